@@ -1,0 +1,154 @@
+/* include/mvo.h — C ABI of libmvo_hip.so: the MI355X-native per-frame VO front-end.
+ *
+ * Drop-in boundary for the hot path of Tatsuya-2/ros2_mono_vo.  The reference has no FFI layer: its
+ * FeatureProcessor / Tracker / Initializer call OpenCV directly.  Each entry point below replaces one
+ * of those OpenCV call sites (cited per function as reference file:line) and is what a maintainer
+ * would bind from the reference's C++ (see INTEGRATION.md for the shim).  POD only, caller-owned
+ * host buffers, int status codes, never throws.  Results follow the OpenCV-4.6 semantics the
+ * reference relies on; parity is checked against oracle/ (test-only).
+ *
+ * Threading: a context is single-threaded (one HIP stream); any number of contexts per process.
+ * All calls are synchronous unless stated: outputs are valid in host memory on return.
+ */
+#ifndef MVO_H_
+#define MVO_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVO_OK 0
+#define MVO_E_ARG 1        /* bad argument / shape (OpenCV would throw cv::Exception) */
+#define MVO_E_CAPACITY 2   /* an output or internal buffer is too small */
+#define MVO_E_HIP 3        /* HIP runtime error (mvo_last_error has the text) */
+#define MVO_E_DEGENERATE 4 /* estimator found no model (OpenCV returns an empty Mat / false) */
+
+typedef struct mvo_ctx mvo_ctx;
+
+/* cv::KeyPoint layout (7 x 4 bytes). */
+typedef struct mvo_keypoint {
+  float x, y, size, angle, response;
+  int octave, class_id;
+} mvo_keypoint;
+
+/* cv::DMatch layout. */
+typedef struct mvo_match {
+  int query_idx, train_idx, img_idx;
+  float distance;
+} mvo_match;
+
+/* Configuration.  Names and defaults mirror the reference's ROS parameters
+ * (include/mono_vo/tracker.hpp:137-147, include/mono_vo/initializer.hpp:109-115) plus the constants
+ * the reference hard-codes (nfeatures: src/mono_vo.cpp:16; ORB / LK defaults come from OpenCV). */
+typedef struct mvo_config {
+  int max_width, max_height; /* largest frame this context will see */
+  int batch;                 /* independent camera streams (slots) resident in the context, >= 1 */
+  int max_points;            /* capacity per slot for tracked points / correspondences */
+  /* ORB (FeatureProcessor ctor, src/feature_processor.cpp:5-10) */
+  int nfeatures;      /* 1000 in the reference */
+  int fast_threshold; /* 20 */
+  int orb_blur_mode;  /* 0: sepFilter2D 8-bit taps (what ORB's in-place sub-matrix blur gets); 1: bit-exact ED taps */
+  /* LK (cv::calcOpticalFlowPyrLK defaults, src/tracker.cpp:68-69) */
+  int lk_channels; /* 3: the reference converts every frame to BGR8 (src/mono_vo.cpp:94) */
+  int lk_win;      /* 21 */
+  int lk_max_level; /* 3 */
+  int lk_max_count; /* 30 */
+  double lk_epsilon; /* 0.01 */
+  double lk_min_eig; /* 1e-4 */
+  /* Tracker parameters (include/mono_vo/tracker.hpp:137-147) */
+  float tracking_error_thresh;                   /* 30.0 */
+  int64_t min_observations_before_triangulation; /* 100 */
+  int64_t min_tracked_points;                    /* 10 */
+  int64_t max_tracking_after_keyframe;           /* 10 */
+  double max_rotation_from_keyframe;             /* 15 deg in rad */
+  double max_translation_from_keyframe;          /* 1.0 */
+  double ransac_reproj_thresh;                   /* 1.0 (H / F) */
+  double model_score_thresh;                     /* 0.85 tracker */
+  double f_inlier_thresh;                        /* 0.5 */
+  double lowes_distance_ratio;                   /* 0.7 */
+  /* Initializer parameters (include/mono_vo/initializer.hpp:109-115) */
+  int occupancy_grid_div;             /* 50 */
+  double kp_distribution_thresh;      /* 0.5 */
+  int64_t min_matches_for_init;       /* 100 */
+  double init_model_score_thresh;     /* 0.56 */
+  /* plumbing */
+  void* hip_stream;       /* optional caller-owned hipStream_t; NULL = the context creates one */
+  const int* orb_pattern; /* optional 1024 ints replacing the built-in rBRIEF pattern */
+  int device;             /* HIP device ordinal, -1 = current */
+} mvo_config;
+
+void mvo_config_default(mvo_config* cfg);
+int mvo_create(const mvo_config* cfg, mvo_ctx** out);
+void mvo_destroy(mvo_ctx* ctx);
+const char* mvo_last_error(const mvo_ctx* ctx);
+const char* mvo_version(void);
+/* Blocks until all work queued on the context's stream has finished. */
+int mvo_sync(mvo_ctx* ctx);
+/* The hipStream_t the context launches on (for HIP-event timing by the caller). */
+void* mvo_stream(mvo_ctx* ctx);
+
+/* ---- a1: FeatureProcessor::detect_and_compute (src/feature_processor.cpp:19-23) ------------------
+ * cv::ORB::detectAndCompute(img, noArray(), kps, desc).  img: mono8 (channels 1) or BGR8 (3).
+ * Writes min(*n, cap) keypoints and 32-byte descriptors; *n is the full count (may exceed nfeatures
+ * on score ties, as in OpenCV).  Key-point order is OpenCV's (KeyPointsFilter::retainBest order). */
+int mvo_orb_detect_and_compute(mvo_ctx* ctx, const uint8_t* img, int w, int h, int stride, int channels,
+                               mvo_keypoint* kps, uint8_t* desc, int cap, int* n);
+/* FeatureProcessor::detect (src/feature_processor.cpp:12-17; no callers in the reference). */
+int mvo_orb_detect(mvo_ctx* ctx, const uint8_t* img, int w, int h, int stride, int channels,
+                   mvo_keypoint* kps, int cap, int* n);
+/* Building block exposed for parity tests: FAST-9/16 + 3x3 NMS on one mono8 image, row-major
+ * (x, y, score) triples, as cv::FAST(img, kps, threshold, true). */
+int mvo_fast9_nms(mvo_ctx* ctx, const uint8_t* img, int w, int h, int stride, int threshold, int* xys,
+                  int cap, int* n);
+
+/* ---- a2: FeatureProcessor::find_matches (src/feature_processor.cpp:25-41) ------------------------
+ * BFMatcher(NORM_HAMMING).knnMatch(q, t, 2) + Lowe ratio (m[0].distance < ratio * m[1].distance). */
+int mvo_match_knn2_ratio(mvo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, double ratio,
+                         mvo_match* out, int cap, int* n);
+
+/* ---- a3: Tracker::track_frame_with_optical_flow (src/tracker.cpp:58-90) -------------------------
+ * cv::calcOpticalFlowPyrLK(prev, next, prev_pts, next_pts, status, err) with default arguments.
+ * Images mono8 or BGR8 with identical channels (the reference's mono8->BGR8 case); cfg.lk_channels
+ * carries the channel count semantics. */
+int mvo_lk_track(mvo_ctx* ctx, const uint8_t* prev, const uint8_t* next, int w, int h, int stride,
+                 int channels, const float* prev_pts, int n, float* next_pts, uint8_t* status, float* err);
+/* cv::pyrDown building block (parity tests). dst is ((w+1)/2) x ((h+1)/2). */
+int mvo_pyrdown(mvo_ctx* ctx, const uint8_t* src, int w, int h, int stride, uint8_t* dst, int dstride);
+
+/* ---- a5: Tracker::has_parallax / Initializer::check_parallax (src/tracker.cpp:237-268,
+ * src/initializer.cpp:77-110) ----------------------------------------------------------------------
+ * cv::findHomography(p1, p2, RANSAC, thr, mask) (max_iters 2000, confidence 0.995) — mask is the
+ * RANSAC consensus mask (0/1); H is the consensus model before OpenCV's LM polish (the reference
+ * discards H).  Returns MVO_E_DEGENERATE with an all-zero mask when no model is found. */
+int mvo_find_homography_ransac(mvo_ctx* ctx, const float* p1, const float* p2, int n, double thr,
+                               int max_iters, double confidence, uint8_t* mask, double H[9], int* n_inliers);
+/* cv::findFundamentalMat(p1, p2, FM_RANSAC, thr, confidence, mask) (7-point, max_iters 1000). */
+int mvo_find_fundamental_ransac(mvo_ctx* ctx, const float* p1, const float* p2, int n, double thr,
+                                double confidence, int max_iters, uint8_t* mask, double F[9],
+                                int* n_inliers);
+
+/* ---- a4: Tracker::update PnP section (src/tracker.cpp:300-316) -----------------------------------
+ * cv::solvePnPRansac(obj, img, K, d, rvec, tvec, false, iters, reproj, conf, inliers). */
+int mvo_solve_pnp_ransac(mvo_ctx* ctx, const float* obj, const float* img, int n, const double K[9],
+                         const double d[5], int iters, float reproj_err, double confidence, double rvec[3],
+                         double tvec[3], int* inlier_idx, int* n_inliers);
+
+/* ---- a6: Initializer pose section (src/initializer.cpp:226-249) ----------------------------------
+ * cv::findEssentialMat(p1, p2, K, RANSAC, prob, thr, mask) and cv::recoverPose(E, p1, p2, K, R, t, mask). */
+int mvo_find_essential_ransac(mvo_ctx* ctx, const float* p1, const float* p2, int n, const double K[9],
+                              double prob, double thr, int max_iters, uint8_t* mask, double E[9],
+                              int* n_inliers);
+int mvo_recover_pose(mvo_ctx* ctx, const double E[9], const float* p1, const float* p2, int n,
+                     const double K[9], double R[9], double t[3], uint8_t* mask_io, int* n_good);
+
+/* ---- a7: triangulation (src/tracker.cpp:138-180, src/initializer.cpp:112-163) --------------------
+ * cv::triangulatePoints(P1, P2, p1, p2, X4) + cv::convertPointsFromHomogeneous: X3 is n x 3 float. */
+int mvo_triangulate(mvo_ctx* ctx, const double P1[12], const double P2[12], const float* p1,
+                    const float* p2, int n, float* X3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVO_H_ */

@@ -1,0 +1,97 @@
+"""ctypes loader for the C-ABI library (include/mvo.h).  No CPU fallback: if libmvo_hip.so is missing or
+does not load, importing the product API raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmvo_hip.so")
+
+MVO_OK, MVO_E_ARG, MVO_E_CAPACITY, MVO_E_HIP, MVO_E_DEGENERATE = 0, 1, 2, 3, 4
+_ERR = {1: "MVO_E_ARG", 2: "MVO_E_CAPACITY", 3: "MVO_E_HIP", 4: "MVO_E_DEGENERATE"}
+
+
+class MvoError(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__(f"{_ERR.get(code, code)}: {msg}")
+        self.code = code
+
+
+class Config(C.Structure):
+    """Mirror of `mvo_config` (include/mvo.h)."""
+    _fields_ = [
+        ("max_width", C.c_int), ("max_height", C.c_int), ("batch", C.c_int), ("max_points", C.c_int),
+        ("nfeatures", C.c_int), ("fast_threshold", C.c_int), ("orb_blur_mode", C.c_int),
+        ("lk_channels", C.c_int), ("lk_win", C.c_int), ("lk_max_level", C.c_int), ("lk_max_count", C.c_int),
+        ("lk_epsilon", C.c_double), ("lk_min_eig", C.c_double),
+        ("tracking_error_thresh", C.c_float),
+        ("min_observations_before_triangulation", C.c_int64), ("min_tracked_points", C.c_int64),
+        ("max_tracking_after_keyframe", C.c_int64),
+        ("max_rotation_from_keyframe", C.c_double), ("max_translation_from_keyframe", C.c_double),
+        ("ransac_reproj_thresh", C.c_double), ("model_score_thresh", C.c_double),
+        ("f_inlier_thresh", C.c_double), ("lowes_distance_ratio", C.c_double),
+        ("occupancy_grid_div", C.c_int), ("kp_distribution_thresh", C.c_double),
+        ("min_matches_for_init", C.c_int64), ("init_model_score_thresh", C.c_double),
+        ("hip_stream", C.c_void_p), ("orb_pattern", C.c_void_p), ("device", C.c_int),
+    ]
+
+
+KP_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("size", "f4"), ("angle", "f4"), ("response", "f4"),
+                     ("octave", "i4"), ("class_id", "i4")])
+MATCH_DTYPE = np.dtype([("query_idx", "i4"), ("train_idx", "i4"), ("img_idx", "i4"), ("distance", "f4")])
+
+# every symbol include/mvo.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "mvo_config_default", "mvo_create", "mvo_destroy", "mvo_last_error", "mvo_version", "mvo_sync", "mvo_stream",
+    "mvo_orb_detect_and_compute", "mvo_orb_detect", "mvo_fast9_nms", "mvo_match_knn2_ratio", "mvo_lk_track",
+    "mvo_pyrdown", "mvo_find_homography_ransac", "mvo_find_fundamental_ransac", "mvo_solve_pnp_ransac",
+    "mvo_find_essential_ransac", "mvo_recover_pose", "mvo_triangulate",
+]
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile libmvo_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4"]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.mvo_last_error.restype = C.c_char_p
+        L.mvo_last_error.argtypes = [C.c_void_p]
+        L.mvo_version.restype = C.c_char_p
+        L.mvo_stream.restype = C.c_void_p
+        L.mvo_stream.argtypes = [C.c_void_p]
+        L.mvo_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+        L.mvo_destroy.argtypes = [C.c_void_p]
+        L.mvo_destroy.restype = None
+        L.mvo_sync.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def default_config(**kw) -> Config:
+    c = Config()
+    lib().mvo_config_default(C.byref(c))
+    for k, v in kw.items():
+        if not hasattr(c, k):
+            raise AttributeError(k)
+        setattr(c, k, v)
+    return c
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p)

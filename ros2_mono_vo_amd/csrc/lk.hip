@@ -1,0 +1,393 @@
+// csrc/lk.hip — pyramidal Lucas-Kanade optical flow for gfx950 (replaces cv::calcOpticalFlowPyrLK at
+// reference src/tracker.cpp:68-69; semantics per SURVEY.md Appendix A.3).
+//
+// Kernels
+//   pyrdown_kernel : cv::pyrDown ([1 4 6 4 1]^2, (sum+128)>>8, reflect-101), LDS-tiled, one launch per level
+//                    covering every slot of the batch.
+//   lk_track_kernel: ONE WAVEFRONT PER TRACKED POINT, all pyramid levels inside one launch.  Per level the
+//                    wave stages the 24x24 source neighbourhood of the previous image in LDS, derives the
+//                    22x22 Scharr field there, and keeps its 21x21 fixed-point template (I, Ix, Iy) in
+//                    registers: 63 lanes x 7 horizontally adjacent pixels.  The search window of the next
+//                    image is staged as a 32x32 LDS tile that is re-fetched only when the window leaves it.
+//                    Normal-equation sums are exact integers (per-lane int32 partials, int64 wave reduction),
+//                    so results are independent of summation order and bit-identical to the oracle.
+#include "mvo_internal.h"
+
+// ---------------------------------------------------------------------------------------------------
+// pyrDown
+// ---------------------------------------------------------------------------------------------------
+#define PD_TW 64
+#define PD_TH 16
+#define PD_SW (2 * PD_TW + 3)
+#define PD_SH (2 * PD_TH + 3)
+
+__global__ __launch_bounds__(256) void pyrdown_kernel(ImgSet src, ImgSet dst) {
+  __shared__ u8 s_src[PD_SH][PD_SW + 1];
+  __shared__ unsigned short s_h[PD_SH][PD_TW];
+  const u8* sp = src.slot(blockIdx.z);
+  u8* dp = dst.slot(blockIdx.z);
+  int dx0 = blockIdx.x * PD_TW, dy0 = blockIdx.y * PD_TH;
+  int sx0 = 2 * dx0 - 2, sy0 = 2 * dy0 - 2;
+  for (int i = threadIdx.x; i < PD_SH * PD_SW; i += 256) {
+    int ty = i / PD_SW, tx = i - ty * PD_SW;
+    int sx = d_reflect101(sx0 + tx, src.w), sy = d_reflect101(sy0 + ty, src.h);
+    s_src[ty][tx] = sp[(size_t)sy * src.pitch + sx];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < PD_SH * PD_TW; i += 256) {
+    int ty = i / PD_TW, tx = i - ty * PD_TW;
+    const u8* r = &s_src[ty][2 * tx];
+    s_h[ty][tx] = (unsigned short)(r[2] * 6 + (r[1] + r[3]) * 4 + r[0] + r[4]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < PD_TH * PD_TW; i += 256) {
+    int ty = i / PD_TW, tx = i - ty * PD_TW;
+    int x = dx0 + tx, y = dy0 + ty;
+    if (x < dst.w && y < dst.h) {
+      int v = s_h[2 * ty + 2][tx] * 6 + (s_h[2 * ty + 1][tx] + s_h[2 * ty + 3][tx]) * 4 + s_h[2 * ty][tx] +
+              s_h[2 * ty + 4][tx];
+      dp[(size_t)y * dst.pitch + x] = (u8)((v + 128) >> 8);
+    }
+  }
+}
+
+static void launch_pyrdown(mvo_ctx* ctx, const ImgSet& s, const ImgSet& d, int nslots) {
+  dim3 grid((d.w + PD_TW - 1) / PD_TW, (d.h + PD_TH - 1) / PD_TH, nslots);
+  hipLaunchKernelGGL(pyrdown_kernel, grid, dim3(256), 0, ctx->stream, s, d);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LK tracker
+// ---------------------------------------------------------------------------------------------------
+struct LkLevelDesc {
+  const u8* I;  // previous image, level l (slot 0)
+  const u8* J;  // next image
+  int w, h, pitch;
+};
+struct LkArgs {
+  LkLevelDesc lv[MVO_LK_MAX_LEVELS];
+  size_t slot_stride;  // bytes between slots in both pyramid sets
+  int nlevels;         // levels in use (maxLevel + 1)
+  const float* prev_pts;
+  float* next_pts;
+  u8* status;
+  float* err;
+  const int* npts;  // [B]
+  int maxpts;
+  int cn;  // channel-count semantics (see oracle/orc_lk.cpp header)
+  int max_count;
+  double eps2;
+  double min_eig;
+};
+
+#define LK_WIN 21
+#define LK_IT 24          // I tile edge (WIN + 1 bilinear + 2 Scharr halo)
+#define LK_DT 22          // derivative tile edge
+#define LK_JT 32          // J tile edge
+#define LK_JP 36          // J tile pitch (bytes)
+#define LK_JSLACK ((LK_JT - (LK_WIN + 1)) / 2)
+
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+__device__ __forceinline__ void lk_weights(float a, float b, int& w00, int& w01, int& w10, int& w11) {
+  const int W_BITS = 14;
+  w00 = d_cv_round((1.f - a) * (1.f - b) * (1 << W_BITS));
+  w01 = d_cv_round(a * (1.f - b) * (1 << W_BITS));
+  w10 = d_cv_round((1.f - a) * b * (1 << W_BITS));
+  w11 = (1 << W_BITS) - w00 - w01 - w10;
+}
+
+__device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+struct LkWaveLds {
+  u8 it[LK_IT * LK_IT];          // previous-image neighbourhood
+  short2 dt[LK_DT * LK_DT];      // Scharr (dx, dy)
+  u8 jt[LK_JT * LK_JP];          // next-image search tile
+};
+
+__device__ __forceinline__ void load_j_tile(u8* jt, const u8* J, int w, int h, int pitch, int jx0, int jy0,
+                                            int lane) {
+  // 32 x 32 bytes, reflect-101 on both axes; 16 bytes per lane.
+  int row = lane >> 1, c0 = (lane & 1) * 16;
+  int sy = d_reflect101(jy0 + row, h);
+  const u8* rp = J + (size_t)sy * pitch;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    int sx = d_reflect101(jx0 + c0 + i, w);
+    jt[row * LK_JP + c0 + i] = rp[sx];
+  }
+}
+
+// sum over the lane's 7 pixels of J(bilinear) - I, times (Ix, Iy) or abs.
+template <bool ERR>
+__device__ __forceinline__ void lk_accumulate(const u8* jt, int dx, int dy, int r, int x0, bool active,
+                                              int w00, int w01, int w10, int w11, const int* Iv,
+                                              const int* Ixv, const int* Iyv, int& s1, int& s2) {
+  s1 = 0; s2 = 0;
+  if (!active) return;
+  const u8* p0 = jt + (r + dy) * LK_JP + x0 + dx;
+  const u8* p1 = p0 + LK_JP;
+  int a0 = p0[0], b0 = p1[0];
+#pragma unroll
+  for (int i = 0; i < 7; i++) {
+    int a1 = p0[i + 1], b1 = p1[i + 1];
+    int diff = descale(a0 * w00 + a1 * w01 + b0 * w10 + b1 * w11, 14 - 5) - Iv[i];
+    if (ERR) {
+      s1 += abs(diff);
+    } else {
+      s1 += diff * Ixv[i];
+      s2 += diff * Iyv[i];
+    }
+    a0 = a1; b0 = b1;
+  }
+}
+
+__global__ __launch_bounds__(256) void lk_track_kernel(LkArgs A) {
+  __shared__ LkWaveLds lds[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int slot = blockIdx.y;
+  const int p = blockIdx.x * 4 + wave;
+  if (p >= A.npts[slot]) return;  // wave-uniform
+  LkWaveLds& S = lds[wave];
+  const size_t pidx = (size_t)slot * A.maxpts + p;
+  const float ptx = A.prev_pts[2 * pidx], pty = A.prev_pts[2 * pidx + 1];
+  const float FLT_SCALE = 1.f / (1 << 20);
+  const float half = (LK_WIN - 1) * 0.5f;
+  const int r = lane / 3, x0 = (lane - r * 3) * 7;
+  const bool active = lane < 63;
+
+  int status = 1;
+  float errv = 0.f;
+  float sx = 0.f, sy = 0.f;  // nextPts[ptidx] as stored by OpenCV between levels
+
+  for (int level = A.nlevels - 1; level >= 0; level--) {
+    const LkLevelDesc lv = A.lv[level];
+    const u8* I = lv.I + (size_t)slot * A.slot_stride;
+    const u8* J = lv.J + (size_t)slot * A.slot_stride;
+    float px = ptx * (float)(1. / (1 << level));
+    float py = pty * (float)(1. / (1 << level));
+    float nx, ny;
+    if (level == A.nlevels - 1) { nx = px; ny = py; }
+    else { nx = sx * 2.f; ny = sy * 2.f; }
+    sx = nx; sy = ny;
+    px -= half; py -= half;
+    int ipx = d_cv_floor(px), ipy = d_cv_floor(py);
+    if (ipx < -LK_WIN || ipx >= lv.w || ipy < -LK_WIN || ipy >= lv.h) {
+      if (level == 0) { status = 0; errv = 0.f; }
+      continue;
+    }
+    // ---- stage the 24x24 neighbourhood of I (origin ipx-1, ipy-1), reflect-101 -------------------
+    for (int i = lane; i < LK_IT * LK_IT; i += 64) {
+      int ty = i / LK_IT, tx = i - ty * LK_IT;
+      int gx = d_reflect101(ipx - 1 + tx, lv.w), gy = d_reflect101(ipy - 1 + ty, lv.h);
+      S.it[i] = I[(size_t)gy * lv.pitch + gx];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // ---- Scharr field on the 22x22 window-source positions (zero outside the image) --------------
+    for (int i = lane; i < LK_DT * LK_DT; i += 64) {
+      int ty = i / LK_DT, tx = i - ty * LK_DT;
+      int gx = ipx + tx, gy = ipy + ty;
+      short2 d = make_short2(0, 0);
+      if ((unsigned)gx < (unsigned)lv.w && (unsigned)gy < (unsigned)lv.h) {
+        const u8* c = &S.it[(ty + 1) * LK_IT + tx + 1];
+        int l0 = c[-LK_IT - 1], l1 = c[-1], l2 = c[LK_IT - 1];
+        int m0 = c[-LK_IT], m2 = c[LK_IT];
+        int r0 = c[-LK_IT + 1], r1 = c[1], r2 = c[LK_IT + 1];
+        int t0r = (r0 + r2) * 3 + r1 * 10, t0l = (l0 + l2) * 3 + l1 * 10;
+        int t1l = l2 - l0, t1m = m2 - m0, t1r = r2 - r0;
+        d.x = (short)(t0r - t0l);
+        d.y = (short)((t1r + t1l) * 3 + t1m * 10);
+      }
+      S.dt[i] = d;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // ---- template in registers + exact A sums ---------------------------------------------------------
+    int w00, w01, w10, w11;
+    lk_weights(px - ipx, py - ipy, w00, w01, w10, w11);
+    int Iv[7], Ixv[7], Iyv[7];
+    int a11 = 0, a12 = 0, a22 = 0;
+    if (active) {
+      const u8* i0 = &S.it[(r + 1) * LK_IT + x0 + 1];
+      const u8* i1 = i0 + LK_IT;
+      const short2* d0 = &S.dt[r * LK_DT + x0];
+      const short2* d1 = d0 + LK_DT;
+#pragma unroll
+      for (int i = 0; i < 7; i++) {
+        Iv[i] = descale(i0[i] * w00 + i0[i + 1] * w01 + i1[i] * w10 + i1[i + 1] * w11, 14 - 5);
+        short2 e00 = d0[i], e01 = d0[i + 1], e10 = d1[i], e11 = d1[i + 1];
+        int ix = descale(e00.x * w00 + e01.x * w01 + e10.x * w10 + e11.x * w11, 14);
+        int iy = descale(e00.y * w00 + e01.y * w01 + e10.y * w10 + e11.y * w11, 14);
+        Ixv[i] = ix; Iyv[i] = iy;
+        a11 += ix * ix; a12 += ix * iy; a22 += iy * iy;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 7; i++) { Iv[i] = 0; Ixv[i] = 0; Iyv[i] = 0; }
+    }
+    long long sA11 = wave_sum_i64(a11), sA12 = wave_sum_i64(a12), sA22 = wave_sum_i64(a22);
+    float A11 = (float)(sA11 * A.cn) * FLT_SCALE;
+    float A12 = (float)(sA12 * A.cn) * FLT_SCALE;
+    float A22 = (float)(sA22 * A.cn) * FLT_SCALE;
+    float D = A11 * A22 - A12 * A12;
+    float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) /
+                   (float)(2 * LK_WIN * LK_WIN);
+    if ((double)minEig < A.min_eig || D < 1.1920928955078125e-07f) {
+      if (level == 0) status = 0;
+      continue;
+    }
+    D = 1.f / D;
+    nx -= half; ny -= half;
+    float pdx = 0.f, pdy = 0.f;
+    int jx0 = 0, jy0 = 0;
+    bool have_tile = false;
+    for (int j = 0; j < A.max_count; j++) {
+      int inx = d_cv_floor(nx), iny = d_cv_floor(ny);
+      if (inx < -LK_WIN || inx >= lv.w || iny < -LK_WIN || iny >= lv.h) {
+        if (level == 0) status = 0;
+        break;
+      }
+      int ddx = inx - jx0, ddy = iny - jy0;
+      if (!have_tile || ddx < 0 || ddx > LK_JT - (LK_WIN + 1) || ddy < 0 || ddy > LK_JT - (LK_WIN + 1)) {
+        jx0 = inx - LK_JSLACK; jy0 = iny - LK_JSLACK;
+        __builtin_amdgcn_wave_barrier();
+        load_j_tile(S.jt, J, lv.w, lv.h, lv.pitch, jx0, jy0, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        have_tile = true;
+        ddx = LK_JSLACK; ddy = LK_JSLACK;
+      }
+      lk_weights(nx - inx, ny - iny, w00, w01, w10, w11);
+      int s1, s2;
+      lk_accumulate<false>(S.jt, ddx, ddy, r, x0, active, w00, w01, w10, w11, Iv, Ixv, Iyv, s1, s2);
+      long long sb1 = wave_sum_i64(s1), sb2 = wave_sum_i64(s2);
+      float b1 = (float)(sb1 * A.cn) * FLT_SCALE;
+      float b2 = (float)(sb2 * A.cn) * FLT_SCALE;
+      float dx = (A12 * b2 - A22 * b1) * D;
+      float dy = (A12 * b1 - A11 * b2) * D;
+      nx += dx; ny += dy;
+      sx = nx + half; sy = ny + half;
+      if ((double)dx * dx + (double)dy * dy <= A.eps2) break;
+      if (j > 0 && (double)fabsf(dx + pdx) < 0.01 && (double)fabsf(dy + pdy) < 0.01) {
+        sx -= dx * 0.5f;
+        sy -= dy * 0.5f;
+        break;
+      }
+      pdx = dx; pdy = dy;
+    }
+    if (status && level == 0) {
+      float ex = sx - half, ey = sy - half;
+      int inx = d_cv_floor(ex), iny = d_cv_floor(ey);
+      if (inx < -LK_WIN || inx >= lv.w || iny < -LK_WIN || iny >= lv.h) {
+        status = 0;
+      } else {
+        int ddx = inx - jx0, ddy = iny - jy0;
+        if (!have_tile || ddx < 0 || ddx > LK_JT - (LK_WIN + 1) || ddy < 0 || ddy > LK_JT - (LK_WIN + 1)) {
+          jx0 = inx - LK_JSLACK; jy0 = iny - LK_JSLACK;
+          __builtin_amdgcn_wave_barrier();
+          load_j_tile(S.jt, J, lv.w, lv.h, lv.pitch, jx0, jy0, lane);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          ddx = LK_JSLACK; ddy = LK_JSLACK;
+        }
+        lk_weights(ex - inx, ey - iny, w00, w01, w10, w11);
+        int s1, s2;
+        lk_accumulate<true>(S.jt, ddx, ddy, r, x0, active, w00, w01, w10, w11, Iv, Ixv, Iyv, s1, s2);
+        long long se = wave_sum_i64(s1);
+        float errval = (float)(se * A.cn);
+        errv = errval * 1.f / (float)(32 * LK_WIN * A.cn * LK_WIN);
+      }
+    }
+  }
+  if (lane == 0) {
+    A.next_pts[2 * pidx] = sx;
+    A.next_pts[2 * pidx + 1] = sy;
+    A.status[pidx] = (u8)status;
+    A.err[pidx] = errv;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+static ImgSet lk_imgset(mvo_ctx* ctx, int set, const LkLevels& L, int level) {
+  ImgSet s;
+  s.base = ctx->lk_mem[set] + ctx->lk_level_off[level];
+  s.w = L.w[level]; s.h = L.h[level]; s.pitch = L.pitch[level];
+  s.slot_stride = ctx->lk_slot_bytes;
+  return s;
+}
+
+// Build levels 1.. of pyramid set `set` for `nslots` slots (level 0 already resident).
+int lk_build_pyramid(mvo_ctx* ctx, int set, const LkLevels& L, int nslots) {
+  for (int l = 1; l < L.n; l++) launch_pyrdown(ctx, lk_imgset(ctx, set, L, l - 1), lk_imgset(ctx, set, L, l), nslots);
+  return MVO_OK;
+}
+
+// Track d_prev_pts -> d_next_pts for `nslots` slots between pyramid sets prev_set and cur_set.
+int lk_track_device(mvo_ctx* ctx, int prev_set, int cur_set, const LkLevels& L, int nslots, int max_n) {
+  LkArgs A;
+  memset(&A, 0, sizeof(A));
+  for (int l = 0; l < L.n; l++) {
+    ImgSet p = lk_imgset(ctx, prev_set, L, l), c = lk_imgset(ctx, cur_set, L, l);
+    A.lv[l].I = p.base; A.lv[l].J = c.base;
+    A.lv[l].w = L.w[l]; A.lv[l].h = L.h[l]; A.lv[l].pitch = L.pitch[l];
+  }
+  A.slot_stride = ctx->lk_slot_bytes;
+  A.nlevels = L.n;
+  A.prev_pts = ctx->d_prev_pts; A.next_pts = ctx->d_next_pts;
+  A.status = ctx->d_status; A.err = ctx->d_err; A.npts = ctx->d_npts;
+  A.maxpts = ctx->maxpts;
+  A.cn = ctx->cfg.lk_channels < 1 ? 1 : ctx->cfg.lk_channels;
+  int mc = ctx->cfg.lk_max_count; mc = mc < 0 ? 0 : (mc > 100 ? 100 : mc);
+  double eps = ctx->cfg.lk_epsilon; eps = eps < 0 ? 0 : (eps > 10 ? 10 : eps);
+  A.max_count = mc;
+  A.eps2 = eps * eps;
+  A.min_eig = ctx->cfg.lk_min_eig;
+  if (max_n <= 0) return MVO_OK;
+  dim3 grid((max_n + 3) / 4, nslots);
+  hipLaunchKernelGGL(lk_track_kernel, grid, dim3(256), 0, ctx->stream, A);
+  return MVO_OK;
+}
+
+extern "C" int mvo_pyrdown(mvo_ctx* ctx, const uint8_t* src, int w, int h, int stride, uint8_t* dst,
+                           int dstride) {
+  if (!ctx || !src || !dst || w < 2 || h < 2 || w > ctx->maxw || h > ctx->maxh) return MVO_E_ARG;
+  LkLevels L = lk_levels(w, h, 1, 1);
+  ImgSet s = lk_imgset(ctx, 0, L, 0), d = lk_imgset(ctx, 0, L, 1);
+  int rc = upload_gray(ctx, src, w, h, stride, 1, s.base, s.pitch, 0);
+  if (rc) return rc;
+  launch_pyrdown(ctx, s, d, 1);
+  MVO_HIP(hipMemcpy2DAsync(dst, dstride, d.base, d.pitch, d.w, d.h, hipMemcpyDeviceToHost, ctx->stream));
+  MVO_HIP(hipStreamSynchronize(ctx->stream));
+  return MVO_OK;
+}
+
+extern "C" int mvo_lk_track(mvo_ctx* ctx, const uint8_t* prev, const uint8_t* next, int w, int h, int stride,
+                            int channels, const float* prev_pts, int n, float* next_pts, uint8_t* status,
+                            float* err) {
+  if (!ctx || !prev || !next || n < 0 || w > ctx->maxw || h > ctx->maxh || w <= 0 || h <= 0) return MVO_E_ARG;
+  if (n > ctx->maxpts) { ctx->set_error("mvo_lk_track: n exceeds max_points"); return MVO_E_CAPACITY; }
+  if (n == 0) return MVO_OK;
+  if (ctx->cfg.lk_win != LK_WIN) { ctx->set_error("only winSize 21x21 is built"); return MVO_E_ARG; }
+  LkLevels L = lk_levels(w, h, ctx->cfg.lk_win, ctx->cfg.lk_max_level);
+  int rc;
+  ImgSet p0 = lk_imgset(ctx, 0, L, 0), c0 = lk_imgset(ctx, 1, L, 0);
+  if ((rc = upload_gray(ctx, prev, w, h, stride, channels, p0.base, p0.pitch, 0))) return rc;
+  if ((rc = upload_gray(ctx, next, w, h, stride, channels, c0.base, c0.pitch, 0))) return rc;
+  lk_build_pyramid(ctx, 0, L, 1);
+  lk_build_pyramid(ctx, 1, L, 1);
+  MVO_HIP(hipMemcpyAsync(ctx->d_prev_pts, prev_pts, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  MVO_HIP(hipMemcpyAsync(ctx->d_npts, &n, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  lk_track_device(ctx, 0, 1, L, 1, n);
+  MVO_HIP(hipMemcpyAsync(next_pts, ctx->d_next_pts, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  MVO_HIP(hipMemcpyAsync(status, ctx->d_status, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  MVO_HIP(hipMemcpyAsync(err, ctx->d_err, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  MVO_HIP(hipStreamSynchronize(ctx->stream));
+  return MVO_OK;
+}

@@ -1,0 +1,156 @@
+// csrc/mvo_ctx.hip — context lifetime, configuration defaults, image upload.
+#include "mvo_internal.h"
+
+#include <cmath>
+
+extern "C" const char* mvo_version(void) { return "mvo-hip 0.1 (gfx950)"; }
+
+extern "C" void mvo_config_default(mvo_config* c) {
+  memset(c, 0, sizeof(*c));
+  c->max_width = 1280;
+  c->max_height = 720;
+  c->batch = 1;
+  c->max_points = 8192;
+  c->nfeatures = 1000;  // reference src/mono_vo.cpp:16
+  c->fast_threshold = 20;
+  c->orb_blur_mode = 0;
+  c->lk_channels = 3;  // reference src/mono_vo.cpp:94 (everything becomes BGR8)
+  c->lk_win = 21;
+  c->lk_max_level = 3;
+  c->lk_max_count = 30;
+  c->lk_epsilon = 0.01;
+  c->lk_min_eig = 1e-4;
+  // reference include/mono_vo/tracker.hpp:137-147
+  c->tracking_error_thresh = 30.0f;
+  c->min_observations_before_triangulation = 100;
+  c->min_tracked_points = 10;
+  c->max_tracking_after_keyframe = 10;
+  c->max_rotation_from_keyframe = M_PI * 15.0 / 180.0;
+  c->max_translation_from_keyframe = 1.0;
+  c->ransac_reproj_thresh = 1.0;
+  c->model_score_thresh = 0.85;
+  c->f_inlier_thresh = 0.5;
+  c->lowes_distance_ratio = 0.7;
+  // reference include/mono_vo/initializer.hpp:109-115
+  c->occupancy_grid_div = 50;
+  c->kp_distribution_thresh = 0.5;
+  c->min_matches_for_init = 100;
+  c->init_model_score_thresh = 0.56;
+  c->hip_stream = nullptr;
+  c->orb_pattern = nullptr;
+  c->device = -1;
+}
+
+LkLevels lk_levels(int w, int h, int win, int max_level) {
+  LkLevels L;
+  L.n = 1;
+  L.w[0] = w; L.h[0] = h; L.pitch[0] = align_up(w, 64);
+  for (int l = 1; l <= max_level && l < MVO_LK_MAX_LEVELS; l++) {
+    int sw = (L.w[l - 1] + 1) / 2, sh = (L.h[l - 1] + 1) / 2;
+    if (sw <= win || sh <= win) break;  // buildOpticalFlowPyramid early stop
+    L.w[l] = sw; L.h[l] = sh; L.pitch[l] = align_up(sw, 64);
+    L.n = l + 1;
+  }
+  return L;
+}
+
+__global__ void bgr2gray_kernel(const u8* __restrict__ src, int spitch, u8* __restrict__ dst, int dpitch,
+                                int w, int h) {
+  int x = blockIdx.x * blockDim.x + threadIdx.x;
+  int y = blockIdx.y;
+  if (x >= w) return;
+  const u8* p = src + (size_t)y * spitch + 3 * x;
+  // cvtColor(BGR2GRAY) 8-bit: RGB2Gray<uchar>, 15-bit weights BY15=3735 GY15=19235 RY15=9798.
+  dst[(size_t)y * dpitch + x] = (u8)((p[0] * 3735 + p[1] * 19235 + p[2] * 9798 + (1 << 14)) >> 15);
+}
+
+int upload_gray(mvo_ctx* ctx, const uint8_t* img, int w, int h, int stride, int channels, u8* d_dst,
+                int dpitch, int slot) {
+  if (channels == 1) {
+    MVO_HIP(hipMemcpy2DAsync(d_dst, dpitch, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
+  } else if (channels == 3) {
+    u8* st = ctx->d_stage + (size_t)slot * ctx->stage_slot_bytes;
+    int spitch = align_up(w * 3, 64);
+    MVO_HIP(hipMemcpy2DAsync(st, spitch, img, stride, (size_t)w * 3, h, hipMemcpyHostToDevice, ctx->stream));
+    dim3 grid((w + 255) / 256, h);
+    hipLaunchKernelGGL(bgr2gray_kernel, grid, dim3(256), 0, ctx->stream, st, spitch, d_dst, dpitch, w, h);
+  } else {
+    ctx->set_error("channels must be 1 (mono8) or 3 (BGR8)");
+    return MVO_E_ARG;
+  }
+  return MVO_OK;
+}
+
+extern "C" int mvo_create(const mvo_config* cfg, mvo_ctx** out) {
+  if (!cfg || !out) return MVO_E_ARG;
+  if (cfg->max_width < 32 || cfg->max_height < 32 || cfg->batch < 1 || cfg->max_points < 16) return MVO_E_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return MVO_E_HIP;  // fail loudly: no CPU fallback
+  mvo_ctx* ctx = new mvo_ctx();
+  ctx->cfg = *cfg;
+  ctx->B = cfg->batch;
+  ctx->maxw = cfg->max_width;
+  ctx->maxh = cfg->max_height;
+  ctx->maxpts = cfg->max_points;
+  *out = ctx;
+  if (cfg->device >= 0) MVO_HIP(hipSetDevice(cfg->device));
+  if (cfg->hip_stream) {
+    ctx->stream = (hipStream_t)cfg->hip_stream;
+  } else {
+    MVO_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->own_stream = true;
+  }
+  // LK pyramids
+  LkLevels L = lk_levels(ctx->maxw, ctx->maxh, 1, MVO_LK_MAX_LEVELS - 1);  // capacity: all 4 levels
+  size_t off = 0;
+  for (int l = 0; l < MVO_LK_MAX_LEVELS; l++) {
+    ctx->lk_level_off[l] = off;
+    if (l < L.n) off += (size_t)L.pitch[l] * L.h[l];
+    off = (off + 255) & ~(size_t)255;
+  }
+  ctx->lk_slot_bytes = off;
+  for (int i = 0; i < 2; i++) MVO_HIP(hipMalloc(&ctx->lk_mem[i], ctx->lk_slot_bytes * ctx->B));
+  size_t np = (size_t)ctx->B * ctx->maxpts;
+  MVO_HIP(hipMalloc(&ctx->d_prev_pts, np * 2 * sizeof(float)));
+  MVO_HIP(hipMalloc(&ctx->d_next_pts, np * 2 * sizeof(float)));
+  MVO_HIP(hipMalloc(&ctx->d_status, np));
+  MVO_HIP(hipMalloc(&ctx->d_err, np * sizeof(float)));
+  MVO_HIP(hipMalloc(&ctx->d_npts, ctx->B * sizeof(int)));
+  ctx->stage_slot_bytes = (size_t)align_up(ctx->maxw * 3, 64) * ctx->maxh;
+  MVO_HIP(hipMalloc(&ctx->d_stage, ctx->stage_slot_bytes * ctx->B));
+  ctx->h_pin_bytes = (size_t)16 << 20;
+  MVO_HIP(hipHostMalloc(&ctx->h_pin, ctx->h_pin_bytes, hipHostMallocDefault));
+  int rc;
+  if ((rc = orb_state_create(ctx)) != MVO_OK) return rc;
+  if ((rc = match_state_create(ctx)) != MVO_OK) return rc;
+  if ((rc = geom_state_create(ctx)) != MVO_OK) return rc;
+  return MVO_OK;
+}
+
+extern "C" void mvo_destroy(mvo_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  geom_state_destroy(ctx);
+  match_state_destroy(ctx);
+  orb_state_destroy(ctx);
+  for (int i = 0; i < 2; i++) (void)hipFree(ctx->lk_mem[i]);
+  (void)hipFree(ctx->d_prev_pts);
+  (void)hipFree(ctx->d_next_pts);
+  (void)hipFree(ctx->d_status);
+  (void)hipFree(ctx->d_err);
+  (void)hipFree(ctx->d_npts);
+  (void)hipFree(ctx->d_stage);
+  if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" const char* mvo_last_error(const mvo_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int mvo_sync(mvo_ctx* ctx) {
+  if (!ctx) return MVO_E_ARG;
+  MVO_HIP(hipStreamSynchronize(ctx->stream));
+  return MVO_OK;
+}
+
+extern "C" void* mvo_stream(mvo_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }

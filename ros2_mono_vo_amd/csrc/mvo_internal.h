@@ -1,0 +1,103 @@
+// csrc/mvo_internal.h — context layout and helpers shared by the HIP translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mvo.h"
+
+typedef unsigned char u8;
+
+#define MVO_HIP(call)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      ctx->set_error(std::string(#call) + ": " + hipGetErrorString(e_));                     \
+      return MVO_E_HIP;                                                                      \
+    }                                                                                        \
+  } while (0)
+
+static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+// A batch of same-sized mono8 images, one per slot.
+struct ImgSet {
+  u8* base = nullptr;
+  int w = 0, h = 0, pitch = 0;
+  size_t slot_stride = 0;  // bytes between slots
+  __host__ __device__ inline u8* slot(int s) const { return base + (size_t)s * slot_stride; }
+};
+
+#define MVO_LK_MAX_LEVELS 4
+#define MVO_ORB_LEVELS 8
+
+struct mvo_ctx {
+  mvo_config cfg;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  void set_error(const std::string& s) { err = s; }
+
+  int B = 1;       // slots
+  int maxw = 0, maxh = 0, maxpts = 0;
+
+  // ---- LK: two pyramid sets (ping-pong "prev"/"cur") --------------------------------------------
+  u8* lk_mem[2] = {nullptr, nullptr};   // backing store, levels packed per slot
+  size_t lk_slot_bytes = 0;
+  size_t lk_level_off[MVO_LK_MAX_LEVELS] = {0, 0, 0, 0};
+  int lk_cur = 0;  // index of the "cur" set
+  float* d_prev_pts = nullptr;  // [B][maxpts][2]
+  float* d_next_pts = nullptr;
+  u8* d_status = nullptr;       // [B][maxpts]
+  float* d_err = nullptr;       // [B][maxpts]
+  int* d_npts = nullptr;        // [B]
+
+  // ---- staging -------------------------------------------------------------------------------------
+  u8* d_stage = nullptr;  // raw upload staging (BGR or strided input), maxw*maxh*3 per slot
+  size_t stage_slot_bytes = 0;
+  u8* h_pin = nullptr;    // pinned host scratch
+  size_t h_pin_bytes = 0;
+
+  // ---- ORB ------------------------------------------------------------------------------------------
+  struct OrbState* orb = nullptr;
+  // ---- matcher ----------------------------------------------------------------------------------
+  struct MatchState* match = nullptr;
+  // ---- geometry / RANSAC ------------------------------------------------------------------------
+  struct GeomState* geom = nullptr;
+};
+
+// Level geometry helpers (host).
+struct LkLevels {
+  int n;  // number of levels actually used (maxLevel+1 after the <= winSize early stop)
+  int w[MVO_LK_MAX_LEVELS], h[MVO_LK_MAX_LEVELS], pitch[MVO_LK_MAX_LEVELS];
+};
+LkLevels lk_levels(int w, int h, int win, int max_level);
+
+// Implemented per translation unit; called from mvo_create / mvo_destroy.
+int orb_state_create(mvo_ctx* ctx);
+void orb_state_destroy(mvo_ctx* ctx);
+int match_state_create(mvo_ctx* ctx);
+void match_state_destroy(mvo_ctx* ctx);
+int geom_state_create(mvo_ctx* ctx);
+void geom_state_destroy(mvo_ctx* ctx);
+
+// Upload a host image (mono8 or BGR8, arbitrary stride) into a device mono8 ImgSet slot (async on ctx->stream).
+int upload_gray(mvo_ctx* ctx, const uint8_t* img, int w, int h, int stride, int channels, u8* d_dst,
+                int dpitch, int slot);
+
+// ---- device helpers -------------------------------------------------------------------------------
+__device__ __forceinline__ int d_reflect101(int p, int len) {
+  if ((unsigned)p < (unsigned)len) return p;
+  if (len == 1) return 0;
+  do {
+    if (p < 0) p = -p;
+    else p = 2 * (len - 1) - p;
+  } while ((unsigned)p >= (unsigned)len);
+  return p;
+}
+__device__ __forceinline__ int d_cv_round(float v) { return __float2int_rn(v); }
+__device__ __forceinline__ int d_cv_round(double v) { return __double2int_rn(v); }
+__device__ __forceinline__ int d_cv_floor(float v) { return (int)floorf(v); }
+__device__ __forceinline__ int d_cv_floor(double v) { return (int)floor(v); }

@@ -1,0 +1,805 @@
+// csrc/orb.hip — ORB detect + describe for gfx950 (replaces cv::ORB::detectAndCompute at reference
+// src/feature_processor.cpp:19-23; semantics per SURVEY.md Appendix A.1 and oracle/orc_orb.cpp).
+//
+// Device pipeline, every launch covering all slots of the batch:
+//   resize_exact_kernel   8-level pyramid, INTER_LINEAR_EXACT 8.8 x 8.8 fixed point (level l from l-1)
+//   fast_score_kernel     FAST-9/16 corner test + cornerScore, LDS tile with 3-px halo, 1 pixel / lane
+//   nms_rows_kernel<0/1>  3x3 strict NMS + edgeThreshold cull; one wavefront per image row, __ballot +
+//                         popcount give an ORDERED (row-major) compaction: pass 0 counts, pass 1 emits
+//   scan_rows/scan_slots  exclusive scans (rows -> levels -> slots) so candidates of the whole batch are
+//                         one dense array
+//   harris_kernel         7x7 Harris response of every candidate (int sums, f32 response)
+//   [host]                KeyPointsFilter::retainBest twice per level with libstdc++ nth_element/partition
+//                         on the response arrays only: that permutation IS OpenCV's key-point order
+//   ic_angle_kernel       intensity-centroid orientation, one wavefront per key-point, exact int moments
+//   blur7_kernel          7x7 Gaussian in the 8-bit fixed point ORB gets (LDS separable)
+//   brief_kernel          rotated BRIEF, 32 lanes per key-point (one descriptor byte per lane)
+#include "mvo_internal.h"
+
+#include <algorithm>
+#include <cmath>
+
+static const int kOrbPattern31[256 * 4] = {
+#include "orb_pattern_31.inc"
+};
+
+#define ORB_EDGE 31
+#define ORB_PATCH 31
+#define ORB_HALF 15
+
+struct OrbGeom {
+  int nlevels;
+  int w[MVO_ORB_LEVELS], h[MVO_ORB_LEVELS], pitch[MVO_ORB_LEVELS];
+  size_t off[MVO_ORB_LEVELS];  // byte offset of level l inside a slot
+  size_t slot_stride;
+  float scale[MVO_ORB_LEVELS];
+  int quota[MVO_ORB_LEVELS];
+  int row0[MVO_ORB_LEVELS + 1];  // first NMS-row index of level l (rows inside the edge band only)
+  int edge;
+};
+
+struct OrbState {
+  // capacity geometry (max_width x max_height)
+  size_t slot_bytes = 0;
+  u8* d_pyr = nullptr;    // un-blurred pyramid [B][slot_bytes]
+  u8* d_score = nullptr;  // FAST score maps, same layout
+  u8* d_blur = nullptr;   // blurred pyramid, same layout
+  int max_rows = 0;
+  int* d_row_cnt = nullptr;   // [B][max_rows]
+  int* d_row_off = nullptr;   // [B][max_rows]  offset inside the slot's candidate range
+  int* d_lvl_cnt = nullptr;   // [B][8]
+  int* d_slot_tot = nullptr;  // [B]
+  int* d_slot_base = nullptr; // [B+1]
+  int cand_cap = 0;           // dense candidate capacity for the whole batch
+  unsigned short* d_cx = nullptr;
+  unsigned short* d_cy = nullptr;
+  u8* d_cs = nullptr;
+  u8* d_cl = nullptr;      // level of each candidate
+  int* d_cslot = nullptr;  // slot of each candidate
+  float* d_ch = nullptr;   // harris
+  // final key-points
+  int kp_cap = 0;  // dense, whole batch
+  int* d_sel = nullptr;  // selected candidate indices
+  mvo_keypoint* d_kp = nullptr;
+  float* d_kang = nullptr;
+  u8* d_desc = nullptr;
+  char4* d_pattern = nullptr;
+  int* d_umax = nullptr;
+  // pinned host mirrors
+  int* h_counts = nullptr;  // [B][8] + [B+1]
+  u8* h_cs = nullptr;
+  float* h_ch = nullptr;
+  int* h_sel = nullptr;
+  mvo_keypoint* h_kp = nullptr;
+  u8* h_desc = nullptr;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// geometry (host) — OpenCV's float-scale rounding (orb.cpp getScale / detectAndCompute / computeKeyPoints)
+// ---------------------------------------------------------------------------------------------------
+static void orb_geometry(int w, int h, int nfeatures, int edge, OrbGeom& G) {
+  G.nlevels = MVO_ORB_LEVELS;
+  G.edge = edge;
+  double sf = (double)1.2f;
+  size_t off = 0;
+  int rows = 0;
+  for (int l = 0; l < MVO_ORB_LEVELS; l++) {
+    float scale = (float)std::pow(sf, (double)l);
+    float inv = 1.0f / scale;
+    G.scale[l] = scale;
+    G.w[l] = (int)std::lrintf(w * inv);
+    G.h[l] = (int)std::lrintf(h * inv);
+    G.pitch[l] = align_up(G.w[l], 64);
+    G.off[l] = off;
+    off += (size_t)G.pitch[l] * G.h[l];
+    off = (off + 255) & ~(size_t)255;
+    G.row0[l] = rows;
+    bool too_small = (G.h[l] <= edge * 2 || G.w[l] <= edge * 2);
+    rows += too_small ? 0 : G.h[l] - 2 * edge;
+  }
+  G.row0[MVO_ORB_LEVELS] = rows;
+  G.slot_stride = off;
+  float factor = (float)(1.0 / sf);
+  float nd = nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)MVO_ORB_LEVELS));
+  int sum = 0;
+  for (int l = 0; l < MVO_ORB_LEVELS - 1; l++) {
+    G.quota[l] = (int)std::lrintf(nd);
+    sum += G.quota[l];
+    nd *= factor;
+  }
+  G.quota[MVO_ORB_LEVELS - 1] = std::max(nfeatures - sum, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// resize INTER_LINEAR_EXACT (one level from the previous one)
+// ---------------------------------------------------------------------------------------------------
+struct LinAxis {
+  double scale;  // 1 / ((double)dst / src)
+  int src, dst;
+};
+
+// Returns offset and 8-bit coefficient c1 (c0 = 256 - c1); edge = -1 (use src[0]) / +1 (use src[last]) / 0.
+__device__ __forceinline__ void lin_coef(const LinAxis a, int v, int& ofs, int& c1, int& edge) {
+  double fval = a.scale * ((double)v + 0.5) - 0.5;
+  int ival = d_cv_floor(fval);
+  edge = 0; ofs = 0; c1 = 0;
+  if (ival >= 0 && a.src > 1) {
+    if (ival < a.src - 1) {
+      ofs = ival;
+      c1 = d_cv_round((fval - (double)ival) * 256.0);
+    } else {
+      ofs = a.src - 1;
+      edge = 1;
+    }
+  } else {
+    edge = -1;
+  }
+}
+
+// OpenCV marks [0, mn) and [mx, dst) as clamped where mn = max(v+1 | left-clamped v) and
+// mx = min(v | right-clamped v); the coordinate map is monotone, so "v is clamped" is equivalent.
+__global__ __launch_bounds__(256) void resize_exact_kernel(const u8* __restrict__ pyr, size_t slot_stride,
+                                                           size_t soff, int spitch, size_t doff, int dpitch,
+                                                           LinAxis ax, LinAxis ay) {
+  int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= ax.dst || y >= ay.dst) return;
+  const u8* sp = pyr + (size_t)blockIdx.z * slot_stride + soff;
+  u8* dp = const_cast<u8*>(pyr) + (size_t)blockIdx.z * slot_stride + doff;
+  int ox, cx1, ex, oy, cy1, ey;
+  lin_coef(ax, x, ox, cx1, ex);
+  lin_coef(ay, y, oy, cy1, ey);
+  auto hval = [&](int sy) -> unsigned {
+    const u8* r = sp + (size_t)sy * spitch;
+    if (ex < 0) return (unsigned)r[0] << 8;
+    if (ex > 0) return (unsigned)r[ax.src - 1] << 8;
+    return (unsigned)(256 - cx1) * r[ox] + (unsigned)cx1 * r[ox + 1];
+  };
+  unsigned out;
+  if (ey != 0) {
+    unsigned v = hval(ey < 0 ? 0 : ay.src - 1);
+    out = min(255u, (v + 128u) >> 8);
+  } else {
+    unsigned v = hval(oy) * (unsigned)(256 - cy1) + hval(oy + 1) * (unsigned)cy1;
+    out = min(255u, (v + 32768u) >> 16);
+  }
+  dp[(size_t)y * dpitch + x] = (u8)out;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// FAST-9/16 score map
+// ---------------------------------------------------------------------------------------------------
+#define FT_W 64
+#define FT_H 16
+#define FT_P (FT_W + 6 + 2)  // LDS pitch (bytes)
+
+__device__ __forceinline__ bool has9(unsigned m) {
+  unsigned m2 = m | (m << 16);
+  unsigned x = m2 & (m2 >> 1);
+  x &= x >> 2;
+  x &= x >> 4;
+  x &= m2 >> 8;
+  return (x & 0xFFFFu) != 0;
+}
+
+__device__ __forceinline__ int fast_score_px(const u8* c, int t) {
+  // circle offsets (dx,dy) k=0..15 as in fast_score.cpp makeOffsets(16)
+  const int v = c[0];
+  int d[25];
+  d[0] = v - c[3 * FT_P + 0];   d[1] = v - c[3 * FT_P + 1];   d[2] = v - c[2 * FT_P + 2];
+  d[3] = v - c[1 * FT_P + 3];   d[4] = v - c[3];              d[5] = v - c[-1 * FT_P + 3];
+  d[6] = v - c[-2 * FT_P + 2];  d[7] = v - c[-3 * FT_P + 1];  d[8] = v - c[-3 * FT_P + 0];
+  d[9] = v - c[-3 * FT_P - 1];  d[10] = v - c[-2 * FT_P - 2]; d[11] = v - c[-1 * FT_P - 3];
+  d[12] = v - c[-3];            d[13] = v - c[1 * FT_P - 3];  d[14] = v - c[2 * FT_P - 2];
+  d[15] = v - c[3 * FT_P - 1];
+  unsigned mdark = 0, mbright = 0;  // dark: p < v - t  <=> d > t ; bright: p > v + t <=> d < -t
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    mdark |= (unsigned)(d[k] > t) << k;
+    mbright |= (unsigned)(d[k] < -t) << k;
+  }
+  if (!has9(mdark) && !has9(mbright)) return 0;
+#pragma unroll
+  for (int k = 16; k < 25; k++) d[k] = d[k - 16];
+  // cornerScore<16>: max(t, max_arc min d, max_arc min(-d)) - 1 over the 16 arcs of 9 contiguous pixels
+  int mn2[24], mx2[24], mn4[22], mx4[22], mn8[18], mx8[18];
+#pragma unroll
+  for (int k = 0; k < 24; k++) { mn2[k] = min(d[k], d[k + 1]); mx2[k] = max(d[k], d[k + 1]); }
+#pragma unroll
+  for (int k = 0; k < 22; k++) { mn4[k] = min(mn2[k], mn2[k + 2]); mx4[k] = max(mx2[k], mx2[k + 2]); }
+#pragma unroll
+  for (int k = 0; k < 18; k++) { mn8[k] = min(mn4[k], mn4[k + 4]); mx8[k] = max(mx4[k], mx4[k + 4]); }
+  int a0 = t, b0 = -t;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    a0 = max(a0, min(mn8[k], d[k + 8]));
+    b0 = min(b0, max(mx8[k], d[k + 8]));
+  }
+  return max(a0, -b0) - 1;
+}
+
+__global__ __launch_bounds__(256) void fast_score_kernel(const u8* __restrict__ pyr, u8* __restrict__ score,
+                                                         size_t slot_stride, size_t off, int w, int h, int pitch,
+                                                         int threshold) {
+  __shared__ u8 s[(FT_H + 6) * FT_P];
+  const u8* sp = pyr + (size_t)blockIdx.z * slot_stride + off;
+  u8* dp = score + (size_t)blockIdx.z * slot_stride + off;
+  int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
+  for (int i = threadIdx.x; i < (FT_H + 6) * (FT_W + 6); i += 256) {
+    int ty = i / (FT_W + 6), tx = i - ty * (FT_W + 6);
+    int gx = min(max(x0 - 3 + tx, 0), w - 1), gy = min(max(y0 - 3 + ty, 0), h - 1);
+    s[ty * FT_P + tx] = sp[(size_t)gy * pitch + gx];
+  }
+  __syncthreads();
+  int tx = threadIdx.x & 63;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    int ty = (threadIdx.x >> 6) * 4 + q;
+    int x = x0 + tx, y = y0 + ty;
+    if (x < w && y < h) {
+      int sc = 0;
+      if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) sc = fast_score_px(&s[(ty + 3) * FT_P + tx + 3], threshold);
+      dp[(size_t)y * pitch + x] = (u8)sc;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// NMS + ordered compaction
+// ---------------------------------------------------------------------------------------------------
+template <int EMIT>
+__global__ __launch_bounds__(256) void nms_rows_kernel(const u8* __restrict__ score, OrbGeom G, int* __restrict__ row_cnt,
+                                                       const int* __restrict__ row_off,
+                                                       const int* __restrict__ slot_base, int max_rows,
+                                                       unsigned short* __restrict__ cx, unsigned short* __restrict__ cy,
+                                                       u8* __restrict__ cs, u8* __restrict__ cl, int* __restrict__ cslot,
+                                                       int cand_cap) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int slot = blockIdx.y;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= G.row0[G.nlevels]) return;
+  int l = 0;
+#pragma unroll
+  for (int k = 1; k < MVO_ORB_LEVELS; k++) l += (row >= G.row0[k]);
+  const int w = G.w[l], pitch = G.pitch[l];
+  const int y = G.edge + (row - G.row0[l]);
+  const u8* sp = score + (size_t)slot * G.slot_stride + G.off[l] + (size_t)y * pitch;
+  int count = 0;
+  int base = 0;
+  if (EMIT) base = slot_base[slot] + row_off[(size_t)slot * max_rows + row];
+  for (int xb = G.edge; xb < w - G.edge; xb += 64) {
+    int x = xb + lane;
+    bool keep = false;
+    int s = 0;
+    if (x < w - G.edge) {
+      s = sp[x];
+      if (s) {
+        const u8* u = sp - pitch;
+        const u8* d = sp + pitch;
+        keep = s > sp[x - 1] && s > sp[x + 1] && s > u[x - 1] && s > u[x] && s > u[x + 1] && s > d[x - 1] &&
+               s > d[x] && s > d[x + 1];
+      }
+    }
+    unsigned long long m = __ballot(keep);
+    if (EMIT && keep) {
+      int o = base + count + __popcll(m & ((1ull << lane) - 1));
+      if (o < cand_cap) {
+        cx[o] = (unsigned short)x; cy[o] = (unsigned short)y; cs[o] = (u8)s; cl[o] = (u8)l; cslot[o] = slot;
+      }
+    }
+    count += __popcll(m);
+  }
+  if (!EMIT && lane == 0) row_cnt[(size_t)slot * max_rows + row] = count;
+}
+
+// one block per slot: exclusive scan of the row counts (rows of all levels in order), per-level totals.
+__global__ __launch_bounds__(1024) void scan_rows_kernel(const int* __restrict__ row_cnt, int* __restrict__ row_off,
+                                                         OrbGeom G, int max_rows, int* __restrict__ lvl_cnt,
+                                                         int* __restrict__ slot_tot) {
+  __shared__ int s_w[16];
+  __shared__ int s_run;
+  const int slot = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nrows = G.row0[G.nlevels];
+  if (threadIdx.x == 0) s_run = 0;
+  __syncthreads();
+  for (int r0 = 0; r0 < nrows; r0 += 1024) {
+    int r = r0 + threadIdx.x;
+    int v = r < nrows ? row_cnt[(size_t)slot * max_rows + r] : 0;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      int t = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += t;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    int off = s_run;
+    for (int k = 0; k < wave; k++) off += s_w[k];
+    if (r < nrows) row_off[(size_t)slot * max_rows + r] = off + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int k = 0; k < 16; k++) t += s_w[k];
+      s_run += t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) slot_tot[slot] = s_run;
+  // per-level totals = off[row0[l+1]] - off[row0[l]]
+  if (threadIdx.x < G.nlevels) {
+    int l = threadIdx.x;
+    int a = G.row0[l], b = G.row0[l + 1];
+    int oa = a < nrows ? row_off[(size_t)slot * max_rows + a] : s_run;
+    int ob = b < nrows ? row_off[(size_t)slot * max_rows + b] : s_run;
+    if (a == b) { oa = 0; ob = 0; }
+    lvl_cnt[slot * MVO_ORB_LEVELS + l] = ob - oa;
+  }
+}
+
+__global__ void scan_slots_kernel(const int* __restrict__ slot_tot, int* __restrict__ slot_base, int nslots) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int run = 0;
+    for (int s = 0; s < nslots; s++) { slot_base[s] = run; run += slot_tot[s]; }
+    slot_base[nslots] = run;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Harris response (orb.cpp HarrisResponses, blockSize 7, k 0.04)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void harris_kernel(const u8* __restrict__ pyr, OrbGeom G,
+                                                     const unsigned short* __restrict__ cx,
+                                                     const unsigned short* __restrict__ cy, const u8* __restrict__ cl,
+                                                     const int* __restrict__ cslot, const int* __restrict__ slot_base,
+                                                     int nslots, float* __restrict__ ch, int cand_cap) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  int total = min(slot_base[nslots], cand_cap);
+  if (i >= total) return;
+  int l = cl[i], x0 = cx[i], y0 = cy[i];
+  const int pitch = G.pitch[l];
+  const u8* img = pyr + (size_t)cslot[i] * G.slot_stride + G.off[l];
+  int a = 0, b = 0, c = 0;
+  // candidates are >= 31 px inside the level, so the 9x9 footprint never leaves it
+  for (int dy = -3; dy <= 3; dy++) {
+    const u8* r0 = img + (size_t)(y0 + dy - 1) * pitch + x0;
+    const u8* r1 = r0 + pitch;
+    const u8* r2 = r1 + pitch;
+#pragma unroll
+    for (int dx = -3; dx <= 3; dx++) {
+      int Ix = (r1[dx + 1] - r1[dx - 1]) * 2 + (r0[dx + 1] - r0[dx - 1]) + (r2[dx + 1] - r2[dx - 1]);
+      int Iy = (r2[dx] - r0[dx]) * 2 + (r2[dx - 1] - r0[dx - 1]) + (r2[dx + 1] - r0[dx + 1]);
+      a += Ix * Ix; b += Iy * Iy; c += Ix * Iy;
+    }
+  }
+  const float scale = 1.f / ((1 << 2) * 7 * 255.f);
+  const float scale_sq_sq = scale * scale * scale * scale;
+  ch[i] = ((float)a * b - (float)c * c - 0.04f * ((float)a + b) * ((float)a + b)) * scale_sq_sq;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// IC angle: one wavefront per selected key-point
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float d_fast_atan2(float y, float x) {
+  const float p1 = 0.9997878412794807f * (float)(180 / M_PI);
+  const float p3 = -0.3258083974640975f * (float)(180 / M_PI);
+  const float p5 = 0.1555786518463281f * (float)(180 / M_PI);
+  const float p7 = -0.04432655554792128f * (float)(180 / M_PI);
+  const float eps = (float)2.2204460492503131e-16;
+  float ax = fabsf(x), ay = fabsf(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = ay / (ax + eps);
+    c2 = c * c;
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    c = ax / (ay + eps);
+    c2 = c * c;
+    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void ic_angle_kernel(const u8* __restrict__ pyr, OrbGeom G, const int* __restrict__ sel,
+                                                       int nsel, const unsigned short* __restrict__ cx,
+                                                       const unsigned short* __restrict__ cy, const u8* __restrict__ cl,
+                                                       const int* __restrict__ cslot, const float* __restrict__ ch,
+                                                       const int* __restrict__ umax, mvo_keypoint* __restrict__ kp) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int k = blockIdx.x * 4 + wave;
+  if (k >= nsel) return;
+  const int ci = sel[k];
+  const int l = cl[ci], x0 = cx[ci], y0 = cy[ci];
+  const int pitch = G.pitch[l];
+  const u8* c = pyr + (size_t)cslot[ci] * G.slot_stride + G.off[l] + (size_t)y0 * pitch + x0;
+  // lanes 0..30 -> u = lane-15 on row +v / centre row; lanes 32..62 -> row -v
+  const int u = (lane & 31) - ORB_HALF;
+  const bool lo = lane < 32;
+  const bool ulane = (lane & 31) < 31;
+  int m10 = 0, m01 = 0;
+  if (lo && ulane) m10 = u * c[u];
+  for (int v = 1; v <= ORB_HALF; v++) {
+    int d = umax[v];
+    if (ulane && u >= -d && u <= d) {
+      int val = lo ? c[u + v * pitch] : c[u - v * pitch];
+      m10 += u * val;
+      m01 += lo ? v * val : -v * val;
+    }
+  }
+  m10 = wave_sum_i32(m10);
+  m01 = wave_sum_i32(m01);
+  if (lane == 0) {
+    float sf = G.scale[l];
+    mvo_keypoint o;
+    o.x = (float)x0 * sf;
+    o.y = (float)y0 * sf;
+    o.size = ORB_PATCH * sf;
+    o.angle = d_fast_atan2((float)m01, (float)m10);
+    o.response = ch[ci];
+    o.octave = l;
+    o.class_id = -1;
+    kp[k] = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 7x7 Gaussian as ORB gets it (see oracle/orc_orb.cpp header for the OpenCV dispatch argument)
+// ---------------------------------------------------------------------------------------------------
+#define BL_W 64
+#define BL_H 16
+struct BlurTaps { int k[7]; };
+
+__global__ __launch_bounds__(256) void blur7_kernel(const u8* __restrict__ pyr, u8* __restrict__ out, size_t slot_stride,
+                                                    size_t off, int w, int h, int pitch, BlurTaps T) {
+  __shared__ u8 s[(BL_H + 6)][BL_W + 8];
+  __shared__ unsigned short sh[(BL_H + 6)][BL_W];
+  const u8* sp = pyr + (size_t)blockIdx.z * slot_stride + off;
+  u8* dp = out + (size_t)blockIdx.z * slot_stride + off;
+  int x0 = blockIdx.x * BL_W, y0 = blockIdx.y * BL_H;
+  for (int i = threadIdx.x; i < (BL_H + 6) * (BL_W + 6); i += 256) {
+    int ty = i / (BL_W + 6), tx = i - ty * (BL_W + 6);
+    int gx = d_reflect101(x0 - 3 + tx, w), gy = d_reflect101(y0 - 3 + ty, h);
+    s[ty][tx] = sp[(size_t)gy * pitch + gx];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (BL_H + 6) * BL_W; i += 256) {
+    int ty = i / BL_W, tx = i - ty * BL_W;
+    const u8* r = &s[ty][tx];
+    int v = T.k[0] * r[0] + T.k[1] * r[1] + T.k[2] * r[2] + T.k[3] * r[3] + T.k[4] * r[4] + T.k[5] * r[5] + T.k[6] * r[6];
+    sh[ty][tx] = (unsigned short)v;  // <= 257*255 = 65535
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < BL_H * BL_W; i += 256) {
+    int ty = i / BL_W, tx = i - ty * BL_W;
+    int x = x0 + tx, y = y0 + ty;
+    if (x < w && y < h) {
+      int v = 0;
+#pragma unroll
+      for (int t = 0; t < 7; t++) v += T.k[t] * (int)sh[ty + t][tx];
+      dp[(size_t)y * pitch + x] = (u8)min(255, (v + 32768) >> 16);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// rotated BRIEF: 2 key-points per wavefront, one descriptor byte per lane
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void brief_kernel(const u8* __restrict__ blur, OrbGeom G, const int* __restrict__ sel,
+                                                    int nsel, const u8* __restrict__ cl, const int* __restrict__ cslot,
+                                                    const mvo_keypoint* __restrict__ kp, const char4* __restrict__ pattern,
+                                                    u8* __restrict__ desc) {
+  __shared__ char4 s_pat[256];
+  s_pat[threadIdx.x] = pattern[threadIdx.x];
+  __syncthreads();
+  const int k = blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int byte = threadIdx.x & 31;
+  if (k >= nsel) return;
+  const int ci = sel[k];
+  const int l = cl[ci];
+  const mvo_keypoint kpt = kp[k];
+  const int pitch = G.pitch[l];
+  float scale = 1.f / G.scale[l];
+  float angle = kpt.angle;
+  angle *= (float)(M_PI / 180.f);
+  float a = (float)cos((double)angle), b = (float)sin((double)angle);
+  int ccx = d_cv_round(kpt.x * scale), ccy = d_cv_round(kpt.y * scale);
+  const u8* c = blur + (size_t)cslot[ci] * G.slot_stride + G.off[l] + (size_t)ccy * pitch + ccx;
+  int val = 0;
+#pragma unroll
+  for (int t = 0; t < 8; t++) {
+    char4 p = s_pat[byte * 8 + t];
+    float x0 = p.x * a - p.y * b, y0 = p.x * b + p.y * a;
+    float x1 = p.z * a - p.w * b, y1 = p.z * b + p.w * a;
+    int t0 = c[d_cv_round(y0) * pitch + d_cv_round(x0)];
+    int t1 = c[d_cv_round(y1) * pitch + d_cv_round(x1)];
+    val |= (t0 < t1) << t;
+  }
+  desc[(size_t)k * 32 + byte] = (u8)val;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+int orb_state_create(mvo_ctx* ctx) {
+  OrbState* o = new OrbState();
+  ctx->orb = o;
+  OrbGeom G;
+  orb_geometry(ctx->maxw, ctx->maxh, ctx->cfg.nfeatures, 3, G);  // edge 3 = capacity for mvo_fast9_nms too
+  o->slot_bytes = G.slot_stride;
+  o->max_rows = G.row0[MVO_ORB_LEVELS];
+  size_t tot = o->slot_bytes * ctx->B;
+  MVO_HIP(hipMalloc(&o->d_pyr, tot));
+  MVO_HIP(hipMalloc(&o->d_score, tot));
+  MVO_HIP(hipMalloc(&o->d_blur, tot));
+  MVO_HIP(hipMalloc(&o->d_row_cnt, (size_t)ctx->B * o->max_rows * sizeof(int)));
+  MVO_HIP(hipMalloc(&o->d_row_off, (size_t)ctx->B * o->max_rows * sizeof(int)));
+  MVO_HIP(hipMalloc(&o->d_lvl_cnt, (size_t)ctx->B * MVO_ORB_LEVELS * sizeof(int)));
+  MVO_HIP(hipMalloc(&o->d_slot_tot, (size_t)ctx->B * sizeof(int)));
+  MVO_HIP(hipMalloc(&o->d_slot_base, (size_t)(ctx->B + 1) * sizeof(int)));
+  // candidates: NMS leaves at most one survivor per 2x2 block; budget ~1/24 of the pyramid pixels.
+  size_t pix = 0;
+  for (int l = 0; l < MVO_ORB_LEVELS; l++) pix += (size_t)G.w[l] * G.h[l];
+  size_t cap = std::max<size_t>(pix / 24, 16384) * ctx->B;
+  if (cap > (size_t)1 << 28) cap = (size_t)1 << 28;
+  o->cand_cap = (int)cap;
+  MVO_HIP(hipMalloc(&o->d_cx, cap * sizeof(unsigned short)));
+  MVO_HIP(hipMalloc(&o->d_cy, cap * sizeof(unsigned short)));
+  MVO_HIP(hipMalloc(&o->d_cs, cap));
+  MVO_HIP(hipMalloc(&o->d_cl, cap));
+  MVO_HIP(hipMalloc(&o->d_cslot, cap * sizeof(int)));
+  MVO_HIP(hipMalloc(&o->d_ch, cap * sizeof(float)));
+  o->kp_cap = ctx->maxpts * ctx->B;
+  MVO_HIP(hipMalloc(&o->d_sel, (size_t)o->kp_cap * sizeof(int)));
+  MVO_HIP(hipMalloc(&o->d_kp, (size_t)o->kp_cap * sizeof(mvo_keypoint)));
+  MVO_HIP(hipMalloc(&o->d_desc, (size_t)o->kp_cap * 32));
+  MVO_HIP(hipMalloc(&o->d_pattern, 256 * sizeof(char4)));
+  MVO_HIP(hipMalloc(&o->d_umax, 32 * sizeof(int)));
+  {
+    const int* src = ctx->cfg.orb_pattern ? ctx->cfg.orb_pattern : kOrbPattern31;
+    char4 pat[256];
+    for (int i = 0; i < 256; i++) pat[i] = make_char4((char)src[4 * i], (char)src[4 * i + 1], (char)src[4 * i + 2], (char)src[4 * i + 3]);
+    MVO_HIP(hipMemcpy(o->d_pattern, pat, sizeof(pat), hipMemcpyHostToDevice));
+    // orb.cpp computeKeyPoints: u_max of the half-patch-15 disc
+    int umax[32] = {0};
+    const int half = ORB_HALF;
+    int v, v0, vmax = (int)std::floor(half * std::sqrt(2.f) / 2 + 1);
+    int vmin = (int)std::ceil(half * std::sqrt(2.f) / 2);
+    for (v = 0; v <= vmax; ++v) umax[v] = (int)std::lrint(std::sqrt((double)half * half - v * v));
+    for (v = half, v0 = 0; v >= vmin; --v) {
+      while (umax[v0] == umax[v0 + 1]) ++v0;
+      umax[v] = v0;
+      ++v0;
+    }
+    MVO_HIP(hipMemcpy(o->d_umax, umax, sizeof(umax), hipMemcpyHostToDevice));
+  }
+  MVO_HIP(hipHostMalloc(&o->h_counts, (size_t)(ctx->B * (MVO_ORB_LEVELS + 2) + 1) * sizeof(int), hipHostMallocDefault));
+  MVO_HIP(hipHostMalloc(&o->h_cs, cap, hipHostMallocDefault));
+  MVO_HIP(hipHostMalloc(&o->h_ch, cap * sizeof(float), hipHostMallocDefault));
+  MVO_HIP(hipHostMalloc(&o->h_sel, (size_t)o->kp_cap * sizeof(int), hipHostMallocDefault));
+  MVO_HIP(hipHostMalloc(&o->h_kp, (size_t)o->kp_cap * sizeof(mvo_keypoint), hipHostMallocDefault));
+  MVO_HIP(hipHostMalloc(&o->h_desc, (size_t)o->kp_cap * 32, hipHostMallocDefault));
+  return MVO_OK;
+}
+
+void orb_state_destroy(mvo_ctx* ctx) {
+  OrbState* o = ctx->orb;
+  if (!o) return;
+  void* dev[] = {o->d_pyr, o->d_score, o->d_blur, o->d_row_cnt, o->d_row_off, o->d_lvl_cnt, o->d_slot_tot,
+                 o->d_slot_base, o->d_cx, o->d_cy, o->d_cs, o->d_cl, o->d_cslot, o->d_ch, o->d_sel, o->d_kp,
+                 o->d_desc, o->d_pattern, o->d_umax};
+  for (void* p : dev) (void)hipFree(p);
+  void* hst[] = {o->h_counts, o->h_cs, o->h_ch, o->h_sel, o->h_kp, o->h_desc};
+  for (void* p : hst)
+    if (p) (void)hipHostFree(p);
+  delete o;
+  ctx->orb = nullptr;
+}
+
+namespace {
+struct RespIdx { float response; int idx; };
+// KeyPointsFilter::retainBest (features2d/src/keypoint.cpp) on (response, index) pairs.
+void retain_best(std::vector<RespIdx>& k, int n) {
+  if (n >= 0 && k.size() > (size_t)n) {
+    if (n == 0) { k.clear(); return; }
+    std::nth_element(k.begin(), k.begin() + n - 1, k.end(),
+                     [](const RespIdx& a, const RespIdx& b) { return a.response > b.response; });
+    float amb = k[n - 1].response;
+    auto e = std::partition(k.begin() + n, k.end(), [amb](const RespIdx& a) { return a.response >= amb; });
+    k.resize(e - k.begin());
+  }
+}
+}  // namespace
+
+// Stage 1 (device): pyramid (level 0 must already be resident in d_pyr), FAST, NMS, compaction, Harris.
+static int orb_detect_device(mvo_ctx* ctx, const OrbGeom& G, int nslots) {
+  OrbState* o = ctx->orb;
+  hipStream_t st = ctx->stream;
+  for (int l = 1; l < G.nlevels; l++) {
+    LinAxis ax, ay;
+    ax.src = G.w[l - 1]; ax.dst = G.w[l]; ax.scale = 1.0 / ((double)G.w[l] / G.w[l - 1]);
+    ay.src = G.h[l - 1]; ay.dst = G.h[l]; ay.scale = 1.0 / ((double)G.h[l] / G.h[l - 1]);
+    dim3 grid((G.w[l] + 63) / 64, (G.h[l] + 3) / 4, nslots);
+    hipLaunchKernelGGL(resize_exact_kernel, grid, dim3(256), 0, st, o->d_pyr, G.slot_stride, G.off[l - 1], G.pitch[l - 1],
+                       G.off[l], G.pitch[l], ax, ay);
+  }
+  for (int l = 0; l < G.nlevels; l++) {
+    dim3 grid((G.w[l] + FT_W - 1) / FT_W, (G.h[l] + FT_H - 1) / FT_H, nslots);
+    hipLaunchKernelGGL(fast_score_kernel, grid, dim3(256), 0, st, o->d_pyr, o->d_score, G.slot_stride, G.off[l], G.w[l],
+                       G.h[l], G.pitch[l], ctx->cfg.fast_threshold);
+  }
+  int nrows = G.row0[G.nlevels];
+  if (nrows > 0) {
+    dim3 grid((nrows + 3) / 4, nslots);
+    hipLaunchKernelGGL(nms_rows_kernel<0>, grid, dim3(256), 0, st, o->d_score, G, o->d_row_cnt, o->d_row_off,
+                       o->d_slot_base, o->max_rows, o->d_cx, o->d_cy, o->d_cs, o->d_cl, o->d_cslot, o->cand_cap);
+  }
+  hipLaunchKernelGGL(scan_rows_kernel, dim3(nslots), dim3(1024), 0, st, o->d_row_cnt, o->d_row_off, G, o->max_rows,
+                     o->d_lvl_cnt, o->d_slot_tot);
+  hipLaunchKernelGGL(scan_slots_kernel, dim3(1), dim3(64), 0, st, o->d_slot_tot, o->d_slot_base, nslots);
+  if (nrows > 0) {
+    dim3 grid((nrows + 3) / 4, nslots);
+    hipLaunchKernelGGL(nms_rows_kernel<1>, grid, dim3(256), 0, st, o->d_score, G, o->d_row_cnt, o->d_row_off,
+                       o->d_slot_base, o->max_rows, o->d_cx, o->d_cy, o->d_cs, o->d_cl, o->d_cslot, o->cand_cap);
+  }
+  return MVO_OK;
+}
+
+// Fetch per-slot / per-level candidate counts (synchronises). h_counts: [B][8] lvl counts, then [B+1] slot bases.
+static int orb_fetch_counts(mvo_ctx* ctx, int nslots) {
+  OrbState* o = ctx->orb;
+  MVO_HIP(hipMemcpyAsync(o->h_counts, o->d_lvl_cnt, (size_t)nslots * MVO_ORB_LEVELS * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  MVO_HIP(hipMemcpyAsync(o->h_counts + (size_t)nslots * MVO_ORB_LEVELS, o->d_slot_base, (size_t)(nslots + 1) * sizeof(int),
+                         hipMemcpyDeviceToHost, ctx->stream));
+  MVO_HIP(hipStreamSynchronize(ctx->stream));
+  int total = o->h_counts[(size_t)nslots * MVO_ORB_LEVELS + nslots];
+  if (total > o->cand_cap) { ctx->set_error("ORB candidate capacity exceeded"); return MVO_E_CAPACITY; }
+  return MVO_OK;
+}
+
+// Full batched detect (+ optional describe).  Level 0 of each slot must be resident in orb->d_pyr.
+// Outputs land in h_kp / h_desc (dense over slots); kp_base[s]..kp_base[s+1] is slot s's range.
+int orb_run(mvo_ctx* ctx, int w, int h, int nslots, bool describe, std::vector<int>& kp_base) {
+  OrbState* o = ctx->orb;
+  hipStream_t st = ctx->stream;
+  OrbGeom G;
+  orb_geometry(w, h, ctx->cfg.nfeatures, ORB_EDGE, G);
+  G.slot_stride = o->slot_bytes;
+  int rc = orb_detect_device(ctx, G, nslots);
+  if (rc) return rc;
+  if ((rc = orb_fetch_counts(ctx, nslots))) return rc;
+  const int* lvl = o->h_counts;
+  const int* sbase = o->h_counts + (size_t)nslots * MVO_ORB_LEVELS;
+  int total = sbase[nslots];
+  kp_base.assign(nslots + 1, 0);
+  if (total == 0) return MVO_OK;
+  hipLaunchKernelGGL(harris_kernel, dim3((total + 255) / 256), dim3(256), 0, st, o->d_pyr, G, o->d_cx, o->d_cy, o->d_cl,
+                     o->d_cslot, o->d_slot_base, nslots, o->d_ch, o->cand_cap);
+  MVO_HIP(hipMemcpyAsync(o->h_cs, o->d_cs, (size_t)total, hipMemcpyDeviceToHost, st));
+  MVO_HIP(hipMemcpyAsync(o->h_ch, o->d_ch, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, st));
+  MVO_HIP(hipStreamSynchronize(st));
+  // ---- host: OpenCV's two retainBest passes per level, on responses only ---------------------------
+  int nsel = 0;
+  std::vector<RespIdx> k;
+  for (int s = 0; s < nslots; s++) {
+    kp_base[s] = nsel;
+    int off = sbase[s];
+    for (int l = 0; l < G.nlevels; l++) {
+      int cnt = lvl[s * MVO_ORB_LEVELS + l];
+      k.resize(cnt);
+      for (int i = 0; i < cnt; i++) k[i] = {(float)o->h_cs[off + i], off + i};
+      retain_best(k, 2 * G.quota[l]);
+      for (auto& e : k) e.response = o->h_ch[e.idx];
+      retain_best(k, G.quota[l]);
+      if (nsel + (int)k.size() > o->kp_cap) { ctx->set_error("ORB key-point capacity exceeded"); return MVO_E_CAPACITY; }
+      for (auto& e : k) o->h_sel[nsel++] = e.idx;
+      off += cnt;
+    }
+  }
+  kp_base[nslots] = nsel;
+  if (nsel == 0) return MVO_OK;
+  MVO_HIP(hipMemcpyAsync(o->d_sel, o->h_sel, (size_t)nsel * sizeof(int), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(ic_angle_kernel, dim3((nsel + 3) / 4), dim3(256), 0, st, o->d_pyr, G, o->d_sel, nsel, o->d_cx, o->d_cy,
+                     o->d_cl, o->d_cslot, o->d_ch, o->d_umax, o->d_kp);
+  if (describe) {
+    BlurTaps T;
+    static const int k0[7] = {18, 34, 49, 55, 49, 34, 18};
+    static const int k1[7] = {18, 34, 48, 56, 48, 34, 18};
+    for (int i = 0; i < 7; i++) T.k[i] = ctx->cfg.orb_blur_mode ? k1[i] : k0[i];
+    for (int l = 0; l < G.nlevels; l++) {
+      dim3 grid((G.w[l] + BL_W - 1) / BL_W, (G.h[l] + BL_H - 1) / BL_H, nslots);
+      hipLaunchKernelGGL(blur7_kernel, grid, dim3(256), 0, st, o->d_pyr, o->d_blur, G.slot_stride, G.off[l], G.w[l], G.h[l],
+                         G.pitch[l], T);
+    }
+    hipLaunchKernelGGL(brief_kernel, dim3((nsel + 7) / 8), dim3(256), 0, st, o->d_blur, G, o->d_sel, nsel, o->d_cl, o->d_cslot,
+                       o->d_kp, o->d_pattern, o->d_desc);
+    MVO_HIP(hipMemcpyAsync(o->h_desc, o->d_desc, (size_t)nsel * 32, hipMemcpyDeviceToHost, st));
+  }
+  MVO_HIP(hipMemcpyAsync(o->h_kp, o->d_kp, (size_t)nsel * sizeof(mvo_keypoint), hipMemcpyDeviceToHost, st));
+  MVO_HIP(hipStreamSynchronize(st));
+  return MVO_OK;
+}
+
+static int orb_upload(mvo_ctx* ctx, const uint8_t* img, int w, int h, int stride, int channels, int slot) {
+  OrbState* o = ctx->orb;
+  return upload_gray(ctx, img, w, h, stride, channels, o->d_pyr + (size_t)slot * o->slot_bytes, align_up(w, 64), slot);
+}
+
+static int orb_api(mvo_ctx* ctx, const uint8_t* img, int w, int h, int stride, int channels, mvo_keypoint* kps,
+                   uint8_t* desc, int cap, int* n, bool describe) {
+  if (!ctx || !img || !n || w < 1 || h < 1 || w > ctx->maxw || h > ctx->maxh) return MVO_E_ARG;
+  *n = 0;
+  int rc = orb_upload(ctx, img, w, h, stride, channels, 0);
+  if (rc) return rc;
+  std::vector<int> base;
+  if ((rc = orb_run(ctx, w, h, 1, describe, base))) return rc;
+  int cnt = base[1];
+  *n = cnt;
+  int m = cnt < cap ? cnt : cap;
+  if (m > 0) {
+    if (kps) memcpy(kps, ctx->orb->h_kp, (size_t)m * sizeof(mvo_keypoint));
+    if (describe && desc) memcpy(desc, ctx->orb->h_desc, (size_t)m * 32);
+  }
+  return cnt > cap ? MVO_E_CAPACITY : MVO_OK;
+}
+
+extern "C" int mvo_orb_detect_and_compute(mvo_ctx* ctx, const uint8_t* img, int w, int h, int stride, int channels,
+                                          mvo_keypoint* kps, uint8_t* desc, int cap, int* n) {
+  return orb_api(ctx, img, w, h, stride, channels, kps, desc, cap, n, true);
+}
+
+extern "C" int mvo_orb_detect(mvo_ctx* ctx, const uint8_t* img, int w, int h, int stride, int channels,
+                              mvo_keypoint* kps, int cap, int* n) {
+  return orb_api(ctx, img, w, h, stride, channels, kps, nullptr, cap, n, false);
+}
+
+extern "C" int mvo_fast9_nms(mvo_ctx* ctx, const uint8_t* img, int w, int h, int stride, int threshold, int* xys,
+                             int cap, int* n) {
+  if (!ctx || !img || !n || w < 7 || h < 7 || w > ctx->maxw || h > ctx->maxh) return MVO_E_ARG;
+  OrbState* o = ctx->orb;
+  hipStream_t st = ctx->stream;
+  *n = 0;
+  int rc = orb_upload(ctx, img, w, h, stride, 1, 0);
+  if (rc) return rc;
+  // single level, no edge cull: rows/cols 3..dim-4 exactly as cv::FAST
+  OrbGeom G;
+  orb_geometry(w, h, ctx->cfg.nfeatures, 3, G);
+  G.slot_stride = o->slot_bytes;
+  G.nlevels = 1;
+  G.row0[1] = (h <= 6 || w <= 6) ? 0 : h - 6;
+  for (int l = 2; l <= MVO_ORB_LEVELS; l++) G.row0[l] = G.row0[1];
+  dim3 grid((w + FT_W - 1) / FT_W, (h + FT_H - 1) / FT_H, 1);
+  hipLaunchKernelGGL(fast_score_kernel, grid, dim3(256), 0, st, o->d_pyr, o->d_score, G.slot_stride, G.off[0], w, h, G.pitch[0],
+                     threshold);
+  int nrows = G.row0[1];
+  dim3 g2((nrows + 3) / 4, 1);
+  hipLaunchKernelGGL(nms_rows_kernel<0>, g2, dim3(256), 0, st, o->d_score, G, o->d_row_cnt, o->d_row_off, o->d_slot_base,
+                     o->max_rows, o->d_cx, o->d_cy, o->d_cs, o->d_cl, o->d_cslot, o->cand_cap);
+  hipLaunchKernelGGL(scan_rows_kernel, dim3(1), dim3(1024), 0, st, o->d_row_cnt, o->d_row_off, G, o->max_rows, o->d_lvl_cnt,
+                     o->d_slot_tot);
+  hipLaunchKernelGGL(scan_slots_kernel, dim3(1), dim3(64), 0, st, o->d_slot_tot, o->d_slot_base, 1);
+  hipLaunchKernelGGL(nms_rows_kernel<1>, g2, dim3(256), 0, st, o->d_score, G, o->d_row_cnt, o->d_row_off, o->d_slot_base,
+                     o->max_rows, o->d_cx, o->d_cy, o->d_cs, o->d_cl, o->d_cslot, o->cand_cap);
+  int total = 0;
+  MVO_HIP(hipMemcpyAsync(&total, o->d_slot_tot, sizeof(int), hipMemcpyDeviceToHost, st));
+  MVO_HIP(hipStreamSynchronize(st));
+  *n = total;
+  if (total > o->cand_cap) { ctx->set_error("FAST candidate capacity exceeded"); return MVO_E_CAPACITY; }
+  int m = total < cap ? total : cap;
+  if (m > 0) {
+    std::vector<unsigned short> hx(m), hy(m);
+    std::vector<u8> hs(m);
+    MVO_HIP(hipMemcpy(hx.data(), o->d_cx, (size_t)m * 2, hipMemcpyDeviceToHost));
+    MVO_HIP(hipMemcpy(hy.data(), o->d_cy, (size_t)m * 2, hipMemcpyDeviceToHost));
+    MVO_HIP(hipMemcpy(hs.data(), o->d_cs, (size_t)m, hipMemcpyDeviceToHost));
+    for (int i = 0; i < m; i++) { xys[3 * i] = hx[i]; xys[3 * i + 1] = hy[i]; xys[3 * i + 2] = hs[i]; }
+  }
+  return total > cap ? MVO_E_CAPACITY : MVO_OK;
+}

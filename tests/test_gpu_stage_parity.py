@@ -1,0 +1,140 @@
+"""GPU parity tests: HIP path (through the C ABI) vs the CPU oracle on the same seeded inputs.
+Bit-exact for every integer / index / byte result AND for LK (exact-integer normal equations, see
+oracle/orc_lk.cpp).  "vs reference" = vs the CPU restatement of OpenCV-4.6 semantics (real OpenCV
+is unavailable offline: parity unpinned)."""
+import numpy as np
+import pytest
+
+import oracle_py as O
+from ros2_mono_vo_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def frames480():
+    return synth.gen_stream(640, 480, 0x5EED0002, 3)
+
+
+@pytest.fixture(scope="module")
+def frames720():
+    return synth.gen_stream(1280, 720, 0x5EED0003, 2)
+
+
+def test_pyrdown_bitexact(ctx720, frames720):
+    img = frames720[0]
+    for _ in range(3):
+        g = ctx720.pyrdown(img)
+        o = O.pyrdown(img)
+        assert g.shape == o.shape and np.array_equal(g, o)
+        img = o
+    odd = frames720[0][:333, :517]
+    assert np.array_equal(ctx720.pyrdown(odd), O.pyrdown(odd))
+
+
+def test_fast_corner_indices_bitexact(ctx720, frames720, frames480):
+    for img in (frames480[0], frames720[0], frames720[1][:501, :777]):
+        g = ctx720.fast9_nms(img, 20)
+        o = O.fast9_nms(img, 20)
+        assert len(o) > 500
+        assert g.shape == o.shape and np.array_equal(g, o)
+
+
+def test_fast_edge_cases(ctx720):
+    flat = np.full((64, 64), 127, np.uint8)
+    assert len(ctx720.fast9_nms(flat)) == 0
+    rng = np.random.default_rng(3)
+    noise = rng.integers(0, 256, (97, 131), dtype=np.uint8)
+    assert np.array_equal(ctx720.fast9_nms(noise, 20), O.fast9_nms(noise, 20))
+    assert np.array_equal(ctx720.fast9_nms(noise, 60), O.fast9_nms(noise, 60))
+
+
+def _check_orb(ctx, img, nfeat):
+    gk, gd = ctx.orb_detect_and_compute(img)
+    ok, od = O.orb_detect_and_compute(img, nfeat)
+    assert len(ok) >= nfeat * 0.9
+    assert len(gk) == len(ok)
+    for f in ("x", "y", "size", "angle", "response", "octave", "class_id"):
+        assert np.array_equal(gk[f], ok[f]), f
+    assert np.array_equal(gd, od)
+
+
+def test_orb_bitexact_480(ctx480, frames480):
+    _check_orb(ctx480, frames480[0], 1000)
+    _check_orb(ctx480, frames480[2], 1000)
+
+
+def test_orb_bitexact_720(ctx720, frames720):
+    _check_orb(ctx720, frames720[0], 2000)
+
+
+def test_orb_bgr_input(ctx480, frames480):
+    g = frames480[1]
+    bgr = np.stack([g, g, g], -1)
+    gk, gd = ctx480.orb_detect_and_compute(bgr)
+    ok, od = O.orb_detect_and_compute(g, 1000)
+    assert np.array_equal(gk["x"], ok["x"]) and np.array_equal(gd, od)
+    rng = np.random.default_rng(5)
+    col = np.clip(bgr.astype(np.int32) + rng.integers(-20, 20, bgr.shape), 0, 255).astype(np.uint8)
+    gk, gd = ctx480.orb_detect_and_compute(col)
+    ok, od = O.orb_detect_and_compute(col, 1000)
+    assert np.array_equal(gk["x"], ok["x"]) and np.array_equal(gd, od)
+
+
+def test_matcher_bitexact(ctx480, frames480):
+    _, d0 = O.orb_detect_and_compute(frames480[0], 1000)
+    _, d1 = O.orb_detect_and_compute(frames480[1], 1000)
+    g = ctx480.match_knn2_ratio(d0, d1, 0.7)
+    o = O.match_knn2_ratio(d0, d1, 0.7)
+    assert len(o) > 100
+    assert np.array_equal(g, o)
+    # ties + ratio edge: duplicated train rows, ratio 1.0 and tiny sets
+    t = np.concatenate([d1[:50], d1[:50]])
+    assert np.array_equal(ctx480.match_knn2_ratio(d0[:300], t, 1.0), O.match_knn2_ratio(d0[:300], t, 1.0))
+    assert len(ctx480.match_knn2_ratio(d0, d1[:1], 0.7)) == 0      # a single neighbour is dropped
+    assert len(ctx480.match_knn2_ratio(d0[:0], d1, 0.7)) == 0      # empty query
+    assert len(ctx480.match_knn2_ratio(d0, d1[:0], 0.7)) == 0      # empty train
+    rng = np.random.default_rng(11)
+    rq = rng.integers(0, 256, (777, 32), dtype=np.uint8)
+    rt = rng.integers(0, 256, (1333, 32), dtype=np.uint8)
+    assert np.array_equal(ctx480.match_knn2_ratio(rq, rt, 0.95), O.match_knn2_ratio(rq, rt, 0.95))
+
+
+def _check_lk(ctx, a, b, pts):
+    gp, gs, ge = ctx.lk_track(a, b, pts)
+    op, os_, oe = O.lk_track(a, b, pts, cn=3)
+    assert np.array_equal(gs, os_)
+    assert np.array_equal(gp, op)
+    assert np.array_equal(ge, oe)
+    return gp, gs, ge
+
+
+def test_lk_bitexact(ctx720, frames720, frames480):
+    k, _ = O.orb_detect_and_compute(frames720[0], 2000)
+    pts = np.stack([k["x"], k["y"]], 1)
+    p, s, e = _check_lk(ctx720, frames720[0], frames720[1], pts)
+    assert s.mean() > 0.95
+    flow = (p - pts)[s > 0]
+    assert abs(np.median(flow[:, 0]) + 1.5) < 0.2 and abs(np.median(flow[:, 1]) + 0.5) < 0.2
+    k, _ = O.orb_detect_and_compute(frames480[0], 1000)
+    pts = np.stack([k["x"], k["y"]], 1)
+    _check_lk(ctx720, frames480[0], frames480[2], pts)
+
+
+def test_lk_edge_cases(ctx720, frames480):
+    a, b = frames480[0], frames480[1]
+    # border, outside, sub-pixel and flat-texture points
+    pts = np.array([[0, 0], [639, 479], [-5, 10], [700, 100], [3.25, 470.75], [320.5, 240.5], [12, 12], [630, 5]], np.float32)
+    _check_lk(ctx720, a, b, pts)
+    flat = np.full_like(a, 100)
+    gp, gs, ge = _check_lk(ctx720, flat, flat, pts)
+    assert gs.sum() == 0  # minEig test rejects everything
+    # zero motion => zero flow
+    k, _ = O.orb_detect_and_compute(a, 1000)
+    p0 = np.stack([k["x"], k["y"]], 1)[:200]
+    gp, gs, ge = _check_lk(ctx720, a, a, p0)
+    assert np.abs(gp - p0)[gs > 0].max() < 1e-3 and ge[gs > 0].max() == 0
+    # odd-sized image exercising the pyramid early-stop and reflect borders
+    small = a[:101, :87]
+    sp = np.array([[10, 10], [50, 50], [80, 95], [43.5, 20.25]], np.float32)
+    _check_lk(ctx720, small, b[:101, :87], sp)
