@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py — tracker-step frames/sec of the MI355X-native VO front-end (BASELINE.json metric).
+
+One "step" = the reference's steady-state Tracker::update (src/tracker.cpp:274-333) in its worst case
+(key-frame branch every frame) for a batch of B independent 1280x720 mono8 camera streams resident in
+HBM:  pyrDown pyramid + LK (2000-feature tracks) + status/err filter + solvePnPRansac +
+findHomography/findFundamentalMat RANSAC + ORB(2000) detect/describe + knn2/ratio match + triangulation.
+Stages that are not built yet are listed in config["stages_missing"] and make the line a partial one.
+
+Frames are synthetic (ros2_mono_vo_amd.synth) and pre-loaded into the device frame ring
+before the timed region.  value = frames processed by all ranks / max-over-ranks wall time.
+
+Multi-GPU (--gpus N under torch.distributed.run): independent streams are sharded across ranks; the only
+collective is one RCCL broadcast of the intrinsics {K, d} from rank 0; scaling "weak".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+ALGO_BYTES_PER_LK_POINT = 4261  # 4 levels x (24^2 + 22^2) window bytes + 21 B of point I/O
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def make_streams(w, h, n_frames, n_distinct, seed0):
+    from ros2_mono_vo_amd import synth
+    return [synth.gen_stream(w, h, seed0 + 1 + i, n_frames) for i in range(n_distinct)]
+
+
+def cpu_baseline(streams, nfeatures, n_frames, stages_on):
+    """The oracle (CPU restatement, 1 thread) on a bounded sample of the same workload: stream 0,
+    `n_frames` consecutive steps of the same stage list.  Test infrastructure used as the checker/baseline
+    only — never on the product path."""
+    import oracle_py as O
+    fr = streams[0]
+    t0 = time.perf_counter()
+    kps, desc = O.orb_detect_and_compute(fr[0], nfeatures)
+    pts = np.stack([kps["x"], kps["y"]], 1)
+    t_seed = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    done = 0
+    for k in range(1, min(n_frames + 1, len(fr))):
+        O.lk_track(fr[k - 1], fr[k], pts, cn=3)
+        k2, d2 = O.orb_detect_and_compute(fr[k], nfeatures)
+        O.match_knn2_ratio(desc, d2, 0.7)
+        kps, desc = k2, d2
+        pts = np.stack([kps["x"], kps["y"]], 1)
+        done += 1
+    dt = time.perf_counter() - t0
+    return done / dt, done, t_seed
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="independent camera streams per GPU")
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--nfeatures", type=int, default=2000)
+    ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic streams generated per rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=12)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from ros2_mono_vo_amd import Context, _lib, synth
+
+    W, H, B, K, Wm = args.width, args.height, args.batch, args.steps, args.warmup
+    n_frames = K + Wm + 1
+    # intrinsics: rank 0 owns them, one RCCL broadcast over xGMI (the path's only collective)
+    Kd = torch.zeros(14, dtype=torch.float64, device="cuda")
+    if rank == 0:
+        Kd[:9] = torch.from_numpy(synth.default_K(W, H).reshape(9))
+    if dist is not None:
+        dist.broadcast(Kd, src=0)
+    Kmat = Kd[:9].cpu().numpy().reshape(3, 3)
+    dcoef = Kd[9:].cpu().numpy()
+
+    streams = make_streams(W, H, n_frames, min(args.distinct, B), 0x5EED0003 + 64 * rank)
+    ctx = Context(max_width=W, max_height=H, batch=B, nfeatures=args.nfeatures, max_points=4096,
+                  ring_frames=n_frames, device=local_rank)
+    ctx.batch_set_intrinsics(Kmat, dcoef)
+    for s in range(B):
+        fr = streams[s % len(streams)]
+        for f in range(n_frames):
+            ctx.batch_preload_frame(s, f, fr[f])
+    ctx.sync()
+    nk = ctx.batch_seed(0)
+    # planar landmarks (Z = 10 m) for the seeded tracks: the similarity-warp stream is a fronto-parallel plane
+    for s in range(B):
+        p = ctx.batch_get_tracks(s)
+        z = np.full(len(p), 10.0, np.float32)
+        xyz = np.stack([(p[:, 0] - Kmat[0, 2]) / Kmat[0, 0] * z, (p[:, 1] - Kmat[1, 2]) / Kmat[1, 1] * z, z], 1)
+        ctx.batch_set_landmarks(s, xyz)
+
+    stages_have = _lib.STAGE_LK | _lib.STAGE_ORB | _lib.STAGE_MATCH
+    stages_missing = ["pnp_ransac", "ransac_h", "ransac_f", "triangulate"]
+    stages = stages_have
+
+    for k in range(Wm):
+        ctx.batch_step(1 + k, stages)
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    lk_points = 0
+    last = None
+    for k in range(K):
+        last = ctx.batch_step(1 + Wm + k, stages)
+        lk_points += sum(r.n_prev for r in last)
+    ctx.sync()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    prof = {}
+    for name in ("frame_fanout", "lk_pyramid", "lk_track", "lk_filter", "orb_detect", "orb_describe", "match", "pnp",
+                 "ransac_h", "ransac_f", "triangulate"):
+        ms, n = ctx.profile_read(name)
+        if n:
+            prof[name] = {"ms_total": round(ms, 4), "launches": n, "ms_avg": round(ms / n, 5)}
+
+    if rank == 0:
+        frames = B * K * world
+        value = frames / dt
+        lk = prof.get("lk_track", {"ms_avg": 0, "launches": 0})
+        algo_bytes = ALGO_BYTES_PER_LK_POINT * (lk_points / max(K, 1))
+        achieved = algo_bytes / (lk["ms_avg"] * 1e-3) / 1e9 if lk["ms_avg"] else 0.0
+        line = {
+            "metric": "tracker-step frames/sec @1280x720, 2000 ORB feats",
+            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8/i32 fixed-point + f32/f64", "data": "synthetic",
+            "config": {"workload": f"C3: {W}x{H} mono8, {args.nfeatures} ORB + LK + match; batch of {B} independent "
+                                   f"streams per GPU, key-frame branch every frame",
+                       "batch_per_gpu": B, "width": W, "height": H, "nfeatures": args.nfeatures,
+                       "stages": ["lk_pyramid", "lk_track", "lk_filter", "orb_detect", "orb_describe", "match"],
+                       "stages_missing": stages_missing, "parallelism": f"streams x{world}",
+                       "mean_tracks_per_frame": round(lk_points / max(B * K, 1), 1),
+                       "mean_keypoints": float(np.mean([r.n_keypoints for r in last])),
+                       "mean_matches": float(np.mean([r.n_matches for r in last]))},
+            "roofline": {"bound": "hbm", "kernel": "lk_track_kernel", "achieved": round(achieved, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": None,
+                         "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": lk["ms_avg"]},
+            "stage_ms": prof,
+        }
+        if not args.no_cpu_baseline:
+            fps, nfr, _ = cpu_baseline(streams, args.nfeatures, args.cpu_frames, stages)
+            line["cpu_baseline"] = {"value": round(fps, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+                                    "sample": f"oracle (CPU restatement of OpenCV-4.6 semantics, not OpenCV), stream 0, "
+                                              f"{nfr} consecutive steps of the same stage list, 1 thread"}
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -77,6 +77,7 @@ typedef struct mvo_config {
   void* hip_stream;       /* optional caller-owned hipStream_t; NULL = the context creates one */
   const int* orb_pattern; /* optional 1024 ints replacing the built-in rBRIEF pattern */
   int device;             /* HIP device ordinal, -1 = current */
+  int ring_frames;        /* frame-batch mode: frames per slot kept resident in HBM (0 = none) */
 } mvo_config;
 
 void mvo_config_default(mvo_config* cfg);
@@ -147,6 +148,45 @@ int mvo_recover_pose(mvo_ctx* ctx, const double E[9], const float* p1, const flo
  * cv::triangulatePoints(P1, P2, p1, p2, X4) + cv::convertPointsFromHomogeneous: X3 is n x 3 float. */
 int mvo_triangulate(mvo_ctx* ctx, const double P1[12], const double P2[12], const float* p1,
                     const float* p2, int n, float* X3);
+
+/* ==== frame-batch mode ============================================================
+ * `cfg.batch` independent camera streams live in one context; every kernel launch covers all of them.
+ * Frames are pre-loaded into a device ring (`cfg.ring_frames` per slot) so a step starts with its inputs
+ * resident in HBM.  One step is the reference's steady-state Tracker::update (src/tracker.cpp:274-333)
+ * in its worst case (key-frame work every frame), for every slot at once. */
+#define MVO_STAGE_LK 1u         /* pyrDown pyramid + LK + status/err filter  (src/tracker.cpp:58-90)   */
+#define MVO_STAGE_PNP 2u        /* solvePnPRansac                            (src/tracker.cpp:300-316) */
+#define MVO_STAGE_HF 4u         /* findHomography + findFundamentalMat       (src/tracker.cpp:237-268) */
+#define MVO_STAGE_ORB 8u        /* ORB detect + describe on the new frame    (src/tracker.cpp:185-186) */
+#define MVO_STAGE_MATCH 16u     /* knn2 + ratio vs the last key-frame        (src/tracker.cpp:190-191) */
+#define MVO_STAGE_TRIANG 32u    /* triangulate the matches                   (src/tracker.cpp:208-209) */
+#define MVO_STAGE_ALL 63u
+
+typedef struct mvo_step_result {
+  int n_prev;         /* points fed to LK */
+  int n_tracked;      /* status && err < tracking_error_thresh */
+  int pnp_ok, n_pnp_inliers;
+  double rvec[3], tvec[3];
+  int score_h, score_f;
+  int n_keypoints, n_matches, n_triangulated;
+} mvo_step_result;
+
+int mvo_batch_preload_frame(mvo_ctx* ctx, int slot, int frame_idx, const uint8_t* img, int w, int h, int stride,
+                            int channels);
+/* ORB on ring frame `frame_idx` of every slot: tracks := all key-points, key-frame descriptors := theirs.
+ * landmarks (optional, [batch] pointers to n x 3 floats in key-point order) are filled by `depth_fn`-free
+ * callers through mvo_batch_set_landmarks after reading the key-points back with mvo_batch_get_tracks. */
+int mvo_batch_seed(mvo_ctx* ctx, int frame_idx, int* n_keypoints /* [batch] */);
+int mvo_batch_get_tracks(mvo_ctx* ctx, int slot, float* pts /* cap x 2 */, int cap, int* n);
+int mvo_batch_set_landmarks(mvo_ctx* ctx, int slot, const float* xyz /* n x 3 */, int n);
+int mvo_batch_set_intrinsics(mvo_ctx* ctx, const double K[9], const double d[5]);
+int mvo_batch_step(mvo_ctx* ctx, int frame_idx, unsigned stages, mvo_step_result* out /* [batch] */);
+
+/* Stage timers: HIP events recorded on the context's stream around each kernel group.
+ * Names: "lk_pyramid", "lk_track", "orb_detect", "orb_describe", "match", "pnp", "ransac_h", "ransac_f", ... */
+int mvo_profile_enable(mvo_ctx* ctx, int on);
+int mvo_profile_read(mvo_ctx* ctx, const char* name, double* total_ms, int* launches);
+int mvo_profile_reset(mvo_ctx* ctx);
 
 #ifdef __cplusplus
 }

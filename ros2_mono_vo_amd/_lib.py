@@ -36,7 +36,7 @@ class Config(C.Structure):
         ("f_inlier_thresh", C.c_double), ("lowes_distance_ratio", C.c_double),
         ("occupancy_grid_div", C.c_int), ("kp_distribution_thresh", C.c_double),
         ("min_matches_for_init", C.c_int64), ("init_model_score_thresh", C.c_double),
-        ("hip_stream", C.c_void_p), ("orb_pattern", C.c_void_p), ("device", C.c_int),
+        ("hip_stream", C.c_void_p), ("orb_pattern", C.c_void_p), ("device", C.c_int), ("ring_frames", C.c_int),
     ]
 
 
@@ -50,7 +50,19 @@ ABI_SYMBOLS = [
     "mvo_orb_detect_and_compute", "mvo_orb_detect", "mvo_fast9_nms", "mvo_match_knn2_ratio", "mvo_lk_track",
     "mvo_pyrdown", "mvo_find_homography_ransac", "mvo_find_fundamental_ransac", "mvo_solve_pnp_ransac",
     "mvo_find_essential_ransac", "mvo_recover_pose", "mvo_triangulate",
+    "mvo_batch_preload_frame", "mvo_batch_seed", "mvo_batch_get_tracks", "mvo_batch_set_landmarks",
+    "mvo_batch_set_intrinsics", "mvo_batch_step", "mvo_profile_enable", "mvo_profile_read", "mvo_profile_reset",
 ]
+
+
+class StepResult(C.Structure):
+    """Mirror of `mvo_step_result` (include/mvo.h)."""
+    _fields_ = [("n_prev", C.c_int), ("n_tracked", C.c_int), ("pnp_ok", C.c_int), ("n_pnp_inliers", C.c_int),
+                ("rvec", C.c_double * 3), ("tvec", C.c_double * 3), ("score_h", C.c_int), ("score_f", C.c_int),
+                ("n_keypoints", C.c_int), ("n_matches", C.c_int), ("n_triangulated", C.c_int)]
+
+
+STAGE_LK, STAGE_PNP, STAGE_HF, STAGE_ORB, STAGE_MATCH, STAGE_TRIANG, STAGE_ALL = 1, 2, 4, 8, 16, 32, 63
 
 _lib = None
 

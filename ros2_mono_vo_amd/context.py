@@ -119,3 +119,47 @@ class Context:
         out = np.empty(((h + 1) // 2, (w + 1) // 2), np.uint8)
         self._check(self._L.mvo_pyrdown(self._h, ptr(img), w, h, stride, ptr(out), out.shape[1]))
         return out
+
+    # -- frame-batch mode ------------------------------------------------------------------------------
+    def batch_preload_frame(self, slot, frame_idx, img):
+        img, w, h, stride, ch = self._img(img)
+        self._check(self._L.mvo_batch_preload_frame(self._h, int(slot), int(frame_idx), ptr(img), w, h, stride, ch))
+
+    def batch_seed(self, frame_idx):
+        n = np.zeros(int(self.cfg.batch), np.int32)
+        self._check(self._L.mvo_batch_seed(self._h, int(frame_idx), ptr(n)))
+        return n
+
+    def batch_get_tracks(self, slot):
+        cap = int(self.cfg.max_points)
+        pts = np.zeros((cap, 2), np.float32)
+        n = C.c_int(0)
+        self._check(self._L.mvo_batch_get_tracks(self._h, int(slot), ptr(pts), cap, C.byref(n)))
+        return pts[:n.value].copy()
+
+    def batch_set_landmarks(self, slot, xyz):
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        self._check(self._L.mvo_batch_set_landmarks(self._h, int(slot), ptr(xyz), len(xyz)))
+
+    def batch_set_intrinsics(self, K, d=None):
+        K = np.ascontiguousarray(K, np.float64).reshape(9)
+        d = np.zeros(5) if d is None else np.ascontiguousarray(d, np.float64).reshape(5)
+        self._check(self._L.mvo_batch_set_intrinsics(self._h, ptr(K), ptr(d)))
+
+    def batch_step(self, frame_idx, stages=_lib.STAGE_ALL):
+        res = (_lib.StepResult * int(self.cfg.batch))()
+        self._check(self._L.mvo_batch_step(self._h, int(frame_idx), C.c_uint(stages), res))
+        return res
+
+    # -- stage timers ------------------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._check(self._L.mvo_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._check(self._L.mvo_profile_reset(self._h))
+
+    def profile_read(self, name):
+        ms = C.c_double(0)
+        n = C.c_int(0)
+        self._check(self._L.mvo_profile_read(self._h, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value

@@ -10,17 +10,6 @@
 // the comparison done in double like the reference's `float < double * float`.
 #include "mvo_internal.h"
 
-struct MatchState {
-  u8* d_q = nullptr;     // [B][cap][32]
-  u8* d_t = nullptr;
-  unsigned* d_best = nullptr;  // [B][cap][2] packed keys
-  mvo_match* d_out = nullptr;  // [B][cap]
-  int* d_nout = nullptr;       // [B]
-  int* d_nq = nullptr;         // [B]
-  int* d_nt = nullptr;         // [B]
-  int cap = 0;
-};
-
 #define MT_TILE 256  // train rows per LDS tile (8 KB)
 
 __global__ __launch_bounds__(256) void hamming_knn2_kernel(const u8* __restrict__ q, const u8* __restrict__ t,

@@ -39,6 +39,7 @@ extern "C" void mvo_config_default(mvo_config* c) {
   c->hip_stream = nullptr;
   c->orb_pattern = nullptr;
   c->device = -1;
+  c->ring_frames = 0;
 }
 
 LkLevels lk_levels(int w, int h, int win, int max_level) {
@@ -124,12 +125,14 @@ extern "C" int mvo_create(const mvo_config* cfg, mvo_ctx** out) {
   if ((rc = orb_state_create(ctx)) != MVO_OK) return rc;
   if ((rc = match_state_create(ctx)) != MVO_OK) return rc;
   if ((rc = geom_state_create(ctx)) != MVO_OK) return rc;
+  if ((rc = pipe_state_create(ctx)) != MVO_OK) return rc;
   return MVO_OK;
 }
 
 extern "C" void mvo_destroy(mvo_ctx* ctx) {
   if (!ctx) return;
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  pipe_state_destroy(ctx);
   geom_state_destroy(ctx);
   match_state_destroy(ctx);
   orb_state_destroy(ctx);

@@ -66,7 +66,80 @@ struct mvo_ctx {
   struct MatchState* match = nullptr;
   // ---- geometry / RANSAC ------------------------------------------------------------------------
   struct GeomState* geom = nullptr;
+  // ---- frame-batch pipeline ---------------------------------------------------------------------
+  struct PipeState* pipe = nullptr;
+  // ---- stage timers -----------------------------------------------------------------------------
+  struct Prof* prof = nullptr;
 };
+
+// Stage timers (HIP events on ctx->stream).
+void prof_begin(mvo_ctx* ctx, const char* name);
+void prof_end(mvo_ctx* ctx);
+struct ProfScope {
+  mvo_ctx* c;
+  ProfScope(mvo_ctx* ctx, const char* name) : c(ctx) { prof_begin(c, name); }
+  ~ProfScope() { prof_end(c); }
+};
+
+struct OrbGeom {
+  int nlevels;
+  int w[MVO_ORB_LEVELS], h[MVO_ORB_LEVELS], pitch[MVO_ORB_LEVELS];
+  size_t off[MVO_ORB_LEVELS];  // byte offset of level l inside a slot
+  size_t slot_stride;
+  float scale[MVO_ORB_LEVELS];
+  int quota[MVO_ORB_LEVELS];
+  int row0[MVO_ORB_LEVELS + 1];  // first NMS-row index of level l (rows inside the edge band only)
+  int edge;
+};
+
+struct OrbState {
+  // capacity geometry (max_width x max_height)
+  size_t slot_bytes = 0;
+  u8* d_pyr = nullptr;    // un-blurred pyramid [B][slot_bytes]
+  u8* d_score = nullptr;  // FAST score maps, same layout
+  u8* d_blur = nullptr;   // blurred pyramid, same layout
+  int max_rows = 0;
+  int* d_row_cnt = nullptr;   // [B][max_rows]
+  int* d_row_off = nullptr;   // [B][max_rows]  offset inside the slot's candidate range
+  int* d_lvl_cnt = nullptr;   // [B][8]
+  int* d_slot_tot = nullptr;  // [B]
+  int* d_slot_base = nullptr; // [B+1]
+  int cand_cap = 0;           // dense candidate capacity for the whole batch
+  unsigned short* d_cx = nullptr;
+  unsigned short* d_cy = nullptr;
+  u8* d_cs = nullptr;
+  u8* d_cl = nullptr;      // level of each candidate
+  int* d_cslot = nullptr;  // slot of each candidate
+  float* d_ch = nullptr;   // harris
+  // final key-points
+  int kp_cap = 0;  // dense, whole batch
+  int* d_sel = nullptr;  // selected candidate indices
+  mvo_keypoint* d_kp = nullptr;
+  float* d_kang = nullptr;
+  u8* d_desc = nullptr;
+  char4* d_pattern = nullptr;
+  int* d_umax = nullptr;
+  // pinned host mirrors
+  int* h_counts = nullptr;  // [B][8] + [B+1]
+  u8* h_cs = nullptr;
+  float* h_ch = nullptr;
+  int* h_sel = nullptr;
+  mvo_keypoint* h_kp = nullptr;
+  u8* h_desc = nullptr;
+};
+
+
+struct MatchState {
+  u8* d_q = nullptr;     // [B][cap][32]
+  u8* d_t = nullptr;
+  unsigned* d_best = nullptr;  // [B][cap][2] packed keys
+  mvo_match* d_out = nullptr;  // [B][cap]
+  int* d_nout = nullptr;       // [B]
+  int* d_nq = nullptr;         // [B]
+  int* d_nt = nullptr;         // [B]
+  int cap = 0;
+};
+
 
 // Level geometry helpers (host).
 struct LkLevels {
@@ -82,6 +155,15 @@ int match_state_create(mvo_ctx* ctx);
 void match_state_destroy(mvo_ctx* ctx);
 int geom_state_create(mvo_ctx* ctx);
 void geom_state_destroy(mvo_ctx* ctx);
+int pipe_state_create(mvo_ctx* ctx);
+void pipe_state_destroy(mvo_ctx* ctx);
+
+// device-level stage drivers (all slots per launch)
+int lk_build_pyramid(mvo_ctx* ctx, int set, const LkLevels& L, int nslots);
+int lk_track_device(mvo_ctx* ctx, int prev_set, int cur_set, const LkLevels& L, int nslots, int max_n);
+int orb_run(mvo_ctx* ctx, int w, int h, int nslots, bool describe, std::vector<int>& kp_base);
+int match_device(mvo_ctx* ctx, int nslots, int max_nq, double ratio);
+int pipe_geometry_stages(mvo_ctx* ctx, unsigned stages, mvo_step_result* out);
 
 // Upload a host image (mono8 or BGR8, arbitrary stride) into a device mono8 ImgSet slot (async on ctx->stream).
 int upload_gray(mvo_ctx* ctx, const uint8_t* img, int w, int h, int stride, int channels, u8* d_dst,

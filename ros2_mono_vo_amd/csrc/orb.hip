@@ -27,53 +27,6 @@ static const int kOrbPattern31[256 * 4] = {
 #define ORB_PATCH 31
 #define ORB_HALF 15
 
-struct OrbGeom {
-  int nlevels;
-  int w[MVO_ORB_LEVELS], h[MVO_ORB_LEVELS], pitch[MVO_ORB_LEVELS];
-  size_t off[MVO_ORB_LEVELS];  // byte offset of level l inside a slot
-  size_t slot_stride;
-  float scale[MVO_ORB_LEVELS];
-  int quota[MVO_ORB_LEVELS];
-  int row0[MVO_ORB_LEVELS + 1];  // first NMS-row index of level l (rows inside the edge band only)
-  int edge;
-};
-
-struct OrbState {
-  // capacity geometry (max_width x max_height)
-  size_t slot_bytes = 0;
-  u8* d_pyr = nullptr;    // un-blurred pyramid [B][slot_bytes]
-  u8* d_score = nullptr;  // FAST score maps, same layout
-  u8* d_blur = nullptr;   // blurred pyramid, same layout
-  int max_rows = 0;
-  int* d_row_cnt = nullptr;   // [B][max_rows]
-  int* d_row_off = nullptr;   // [B][max_rows]  offset inside the slot's candidate range
-  int* d_lvl_cnt = nullptr;   // [B][8]
-  int* d_slot_tot = nullptr;  // [B]
-  int* d_slot_base = nullptr; // [B+1]
-  int cand_cap = 0;           // dense candidate capacity for the whole batch
-  unsigned short* d_cx = nullptr;
-  unsigned short* d_cy = nullptr;
-  u8* d_cs = nullptr;
-  u8* d_cl = nullptr;      // level of each candidate
-  int* d_cslot = nullptr;  // slot of each candidate
-  float* d_ch = nullptr;   // harris
-  // final key-points
-  int kp_cap = 0;  // dense, whole batch
-  int* d_sel = nullptr;  // selected candidate indices
-  mvo_keypoint* d_kp = nullptr;
-  float* d_kang = nullptr;
-  u8* d_desc = nullptr;
-  char4* d_pattern = nullptr;
-  int* d_umax = nullptr;
-  // pinned host mirrors
-  int* h_counts = nullptr;  // [B][8] + [B+1]
-  u8* h_cs = nullptr;
-  float* h_ch = nullptr;
-  int* h_sel = nullptr;
-  mvo_keypoint* h_kp = nullptr;
-  u8* h_desc = nullptr;
-};
-
 // ---------------------------------------------------------------------------------------------------
 // geometry (host) — OpenCV's float-scale rounding (orb.cpp getScale / detectAndCompute / computeKeyPoints)
 // ---------------------------------------------------------------------------------------------------
@@ -672,7 +625,8 @@ int orb_run(mvo_ctx* ctx, int w, int h, int nslots, bool describe, std::vector<i
   OrbGeom G;
   orb_geometry(w, h, ctx->cfg.nfeatures, ORB_EDGE, G);
   G.slot_stride = o->slot_bytes;
-  int rc = orb_detect_device(ctx, G, nslots);
+  int rc;
+  { ProfScope ps(ctx, "orb_detect"); rc = orb_detect_device(ctx, G, nslots); }
   if (rc) return rc;
   if ((rc = orb_fetch_counts(ctx, nslots))) return rc;
   const int* lvl = o->h_counts;
@@ -709,6 +663,7 @@ int orb_run(mvo_ctx* ctx, int w, int h, int nslots, bool describe, std::vector<i
   hipLaunchKernelGGL(ic_angle_kernel, dim3((nsel + 3) / 4), dim3(256), 0, st, o->d_pyr, G, o->d_sel, nsel, o->d_cx, o->d_cy,
                      o->d_cl, o->d_cslot, o->d_ch, o->d_umax, o->d_kp);
   if (describe) {
+    ProfScope ps(ctx, "orb_describe");
     BlurTaps T;
     static const int k0[7] = {18, 34, 49, 55, 49, 34, 18};
     static const int k1[7] = {18, 34, 48, 56, 48, 34, 18};

@@ -1,0 +1,402 @@
+// csrc/pipeline.hip — frame-batch mode: B independent camera streams resident in one context, one
+// kernel launch per stage for all of them; plus the HIP-event stage timers.
+//
+// The step mirrors the reference's steady-state Tracker::update (src/tracker.cpp:274-333) in its worst
+// case, where the key-frame branch (has_parallax -> add_new_keyframe) runs on every frame:
+//   LK(prev->cur) -> status/err filter -> solvePnPRansac -> findHomography + findFundamentalMat ->
+//   ORB(cur) -> knn2+ratio vs the last key-frame -> triangulate.
+// All per-stream state (previous pyramid, tracked points, landmarks, key-frame descriptors) stays in HBM.
+#include "mvo_internal.h"
+
+#include <map>
+
+// ---------------------------------------------------------------------------------------------------
+// stage timers
+// ---------------------------------------------------------------------------------------------------
+struct Prof {
+  bool on = false;
+  struct Pending { std::string name; hipEvent_t a, b; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> pool;
+  std::map<std::string, std::pair<double, int>> acc;
+  std::vector<Pending> open;
+};
+
+static hipEvent_t prof_event(Prof* p) {
+  if (!p->pool.empty()) { hipEvent_t e = p->pool.back(); p->pool.pop_back(); return e; }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+void prof_begin(mvo_ctx* ctx, const char* name) {
+  Prof* p = ctx->prof;
+  if (!p || !p->on) return;
+  Prof::Pending q;
+  q.name = name; q.a = prof_event(p); q.b = prof_event(p);
+  (void)hipEventRecord(q.a, ctx->stream);
+  p->open.push_back(q);
+}
+
+void prof_end(mvo_ctx* ctx) {
+  Prof* p = ctx->prof;
+  if (!p || !p->on || p->open.empty()) return;
+  Prof::Pending q = p->open.back();
+  p->open.pop_back();
+  (void)hipEventRecord(q.b, ctx->stream);
+  p->pending.push_back(q);
+}
+
+static void prof_collect(mvo_ctx* ctx) {
+  Prof* p = ctx->prof;
+  if (!p) return;
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& q : p->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, q.a, q.b) == hipSuccess) {
+      auto& e = p->acc[q.name];
+      e.first += ms; e.second += 1;
+    }
+    p->pool.push_back(q.a); p->pool.push_back(q.b);
+  }
+  p->pending.clear();
+}
+
+extern "C" int mvo_profile_enable(mvo_ctx* ctx, int on) {
+  if (!ctx) return MVO_E_ARG;
+  if (!ctx->prof) ctx->prof = new Prof();
+  prof_collect(ctx);
+  ctx->prof->on = on != 0;
+  return MVO_OK;
+}
+
+extern "C" int mvo_profile_read(mvo_ctx* ctx, const char* name, double* total_ms, int* launches) {
+  if (!ctx || !name || !ctx->prof) return MVO_E_ARG;
+  prof_collect(ctx);
+  auto it = ctx->prof->acc.find(name);
+  if (total_ms) *total_ms = it == ctx->prof->acc.end() ? 0.0 : it->second.first;
+  if (launches) *launches = it == ctx->prof->acc.end() ? 0 : it->second.second;
+  return MVO_OK;
+}
+
+extern "C" int mvo_profile_reset(mvo_ctx* ctx) {
+  if (!ctx || !ctx->prof) return MVO_E_ARG;
+  prof_collect(ctx);
+  ctx->prof->acc.clear();
+  return MVO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// pipeline state
+// ---------------------------------------------------------------------------------------------------
+struct PipeState {
+  int ring = 0;
+  int w = 0, h = 0, pitch = 0;  // geometry of the frames in the ring (fixed by the first preload)
+  size_t frame_bytes = 0;       // one slot's frame
+  u8* d_ring = nullptr;         // [ring][B][h][pitch]
+  float* d_lm = nullptr;        // [B][maxpts][3] landmark of each tracked point
+  float* d_kf_pts = nullptr;    // [B][maxpts][2] last key-frame position of each tracked point
+  float* d_cur_pts = nullptr;   // compacted survivors of LK
+  float* d_cur_lm = nullptr;
+  float* d_cur_kf = nullptr;
+  int* d_ncur = nullptr;        // [B]
+  float* d_kp_xy = nullptr;     // [B][maxpts][2] key-point positions of the current frame (match train side)
+  float* d_kfkp_xy = nullptr;   // [B][maxpts][2] key-point positions of the last key-frame (match query side)
+  int* h_ints = nullptr;        // pinned scratch
+  double K[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  double dist[5] = {0, 0, 0, 0, 0};
+  bool seeded = false;
+  int trk_max_n = 0;  // host-side bound on the per-slot track count (grid sizing)
+  int kf_max_n = 0;   // host-side bound on the key-frame descriptor count
+};
+
+int pipe_state_create(mvo_ctx* ctx) {
+  PipeState* p = new PipeState();
+  ctx->pipe = p;
+  if (!ctx->prof) ctx->prof = new Prof();
+  p->ring = ctx->cfg.ring_frames;
+  if (p->ring <= 0) return MVO_OK;
+  p->pitch = align_up(ctx->maxw, 64);
+  p->frame_bytes = (size_t)p->pitch * ctx->maxh;
+  size_t np = (size_t)ctx->B * ctx->maxpts;
+  MVO_HIP(hipMalloc(&p->d_ring, p->frame_bytes * ctx->B * p->ring));
+  MVO_HIP(hipMalloc(&p->d_lm, np * 3 * sizeof(float)));
+  MVO_HIP(hipMalloc(&p->d_kf_pts, np * 2 * sizeof(float)));
+  MVO_HIP(hipMalloc(&p->d_cur_pts, np * 2 * sizeof(float)));
+  MVO_HIP(hipMalloc(&p->d_cur_lm, np * 3 * sizeof(float)));
+  MVO_HIP(hipMalloc(&p->d_cur_kf, np * 2 * sizeof(float)));
+  MVO_HIP(hipMalloc(&p->d_ncur, ctx->B * sizeof(int)));
+  MVO_HIP(hipMalloc(&p->d_kp_xy, np * 2 * sizeof(float)));
+  MVO_HIP(hipMalloc(&p->d_kfkp_xy, np * 2 * sizeof(float)));
+  MVO_HIP(hipHostMalloc(&p->h_ints, (size_t)ctx->B * 16 * sizeof(int), hipHostMallocDefault));
+  MVO_HIP(hipMemsetAsync(p->d_lm, 0, np * 3 * sizeof(float), ctx->stream));
+  MVO_HIP(hipMemsetAsync(p->d_kf_pts, 0, np * 2 * sizeof(float), ctx->stream));
+  return MVO_OK;
+}
+
+void pipe_state_destroy(mvo_ctx* ctx) {
+  PipeState* p = ctx->pipe;
+  if (p) {
+    void* dev[] = {p->d_ring, p->d_lm, p->d_kf_pts, p->d_cur_pts, p->d_cur_lm, p->d_cur_kf, p->d_ncur, p->d_kp_xy, p->d_kfkp_xy};
+    for (void* q : dev) (void)hipFree(q);
+    if (p->h_ints) (void)hipHostFree(p->h_ints);
+    delete p;
+    ctx->pipe = nullptr;
+  }
+  if (ctx->prof) {
+    prof_collect(ctx);
+    for (auto e : ctx->prof->pool) (void)hipEventDestroy(e);
+    delete ctx->prof;
+    ctx->prof = nullptr;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------------
+// ring frame -> LK "cur" level 0 and ORB level 0 (read once, write twice; 16 B per lane)
+__global__ __launch_bounds__(256) void ring_to_level0_kernel(const u8* __restrict__ ring, size_t ring_slot_stride, int pitch,
+                                                             int h, u8* __restrict__ lk0, size_t lk_slot_stride,
+                                                             u8* __restrict__ orb0, size_t orb_slot_stride) {
+  const int slot = blockIdx.y;
+  const size_t n16 = (size_t)pitch * h / 16;
+  const uint4* s = (const uint4*)(ring + (size_t)slot * ring_slot_stride);
+  uint4* a = (uint4*)(lk0 + (size_t)slot * lk_slot_stride);
+  uint4* b = (uint4*)(orb0 + (size_t)slot * orb_slot_stride);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+    uint4 v = s[i];
+    a[i] = v;
+    b[i] = v;
+  }
+}
+
+// Tracker::track_frame_with_optical_flow's keep rule (src/tracker.cpp:70-77): status && err < thresh,
+// order preserved.  One block per slot.
+__global__ __launch_bounds__(1024) void lk_filter_compact_kernel(const float* __restrict__ next_pts, const u8* __restrict__ status,
+                                                                 const float* __restrict__ err, const int* __restrict__ npts,
+                                                                 const float* __restrict__ lm, const float* __restrict__ kf,
+                                                                 float thresh, int maxpts, float* __restrict__ o_pts,
+                                                                 float* __restrict__ o_lm, float* __restrict__ o_kf,
+                                                                 int* __restrict__ o_n) {
+  __shared__ int s_wave[16];
+  __shared__ int s_base;
+  const int slot = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = npts[slot];
+  const size_t b = (size_t)slot * maxpts;
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += 1024) {
+    int i = i0 + threadIdx.x;
+    bool keep = i < n && status[b + i] && err[b + i] < thresh;
+    unsigned long long m = __ballot(keep);
+    int pre = __popcll(m & ((1ull << lane) - 1));
+    if (lane == 0) s_wave[wave] = __popcll(m);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wave; w++) off += s_wave[w];
+    if (keep) {
+      size_t o = b + off + pre;
+      o_pts[2 * o] = next_pts[2 * (b + i)]; o_pts[2 * o + 1] = next_pts[2 * (b + i) + 1];
+      o_lm[3 * o] = lm[3 * (b + i)]; o_lm[3 * o + 1] = lm[3 * (b + i) + 1]; o_lm[3 * o + 2] = lm[3 * (b + i) + 2];
+      o_kf[2 * o] = kf[2 * (b + i)]; o_kf[2 * o + 1] = kf[2 * (b + i) + 1];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int w = 0; w < 16; w++) t += s_wave[w];
+      s_base += t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) o_n[slot] = s_base;
+}
+
+// dense ORB output (all slots back to back) -> per-slot matcher / track layout
+__global__ __launch_bounds__(256) void scatter_kp_kernel(const mvo_keypoint* __restrict__ kp, const u8* __restrict__ desc,
+                                                         const int* __restrict__ kp_base, int maxpts, u8* __restrict__ t_desc,
+                                                         int* __restrict__ t_n, float* __restrict__ kp_xy) {
+  const int slot = blockIdx.y;
+  const int b0 = kp_base[slot], n = kp_base[slot + 1] - b0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) t_n[slot] = n;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n * 8; i += gridDim.x * 256) {
+    int k = i >> 3, q = i & 7;
+    ((unsigned*)t_desc)[((size_t)slot * maxpts + k) * 8 + q] = ((const unsigned*)desc)[(size_t)(b0 + k) * 8 + q];
+    if (q == 0) {
+      kp_xy[2 * ((size_t)slot * maxpts + k)] = kp[b0 + k].x;
+      kp_xy[2 * ((size_t)slot * maxpts + k) + 1] = kp[b0 + k].y;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// API
+// ---------------------------------------------------------------------------------------------------
+extern "C" int mvo_batch_set_intrinsics(mvo_ctx* ctx, const double K[9], const double d[5]) {
+  if (!ctx || !K || !ctx->pipe) return MVO_E_ARG;
+  memcpy(ctx->pipe->K, K, 9 * sizeof(double));
+  if (d) memcpy(ctx->pipe->dist, d, 5 * sizeof(double));
+  return MVO_OK;
+}
+
+extern "C" int mvo_batch_preload_frame(mvo_ctx* ctx, int slot, int frame_idx, const uint8_t* img, int w, int h,
+                                       int stride, int channels) {
+  if (!ctx || !img || !ctx->pipe) return MVO_E_ARG;
+  PipeState* p = ctx->pipe;
+  if (p->ring <= 0 || slot < 0 || slot >= ctx->B || frame_idx < 0 || frame_idx >= p->ring) return MVO_E_ARG;
+  if (w > ctx->maxw || h > ctx->maxh || w < 32 || h < 32) return MVO_E_ARG;
+  if (p->w == 0) { p->w = w; p->h = h; p->pitch = align_up(w, 64); }
+  if (w != p->w || h != p->h) { ctx->set_error("all ring frames must share one size"); return MVO_E_ARG; }
+  u8* dst = p->d_ring + ((size_t)frame_idx * ctx->B + slot) * p->frame_bytes;
+  return upload_gray(ctx, img, w, h, stride, channels, dst, p->pitch, slot);
+}
+
+static int pipe_load_frame(mvo_ctx* ctx, int frame_idx, int lk_set) {
+  PipeState* p = ctx->pipe;
+  OrbState* o = ctx->orb;
+  ProfScope ps(ctx, "frame_fanout");
+  const u8* src = p->d_ring + (size_t)frame_idx * ctx->B * p->frame_bytes;
+  dim3 grid(64, ctx->B);
+  hipLaunchKernelGGL(ring_to_level0_kernel, grid, dim3(256), 0, ctx->stream, src, p->frame_bytes, p->pitch, p->h,
+                     ctx->lk_mem[lk_set] + ctx->lk_level_off[0], ctx->lk_slot_bytes, o->d_pyr, o->slot_bytes);
+  return MVO_OK;
+}
+
+// After ORB on the current frame: publish key-points as the matcher's train set and the frame's positions.
+static int pipe_publish_orb(mvo_ctx* ctx, const std::vector<int>& kp_base, int* max_n) {
+  PipeState* p = ctx->pipe;
+  OrbState* o = ctx->orb;
+  MatchState* m = ctx->match;
+  int B = ctx->B;
+  int* hb = p->h_ints;
+  int mx = 0;
+  for (int s = 0; s <= B; s++) hb[s] = kp_base[s];
+  for (int s = 0; s < B; s++) {
+    int n = kp_base[s + 1] - kp_base[s];
+    if (n > ctx->maxpts) { ctx->set_error("key-points exceed max_points"); return MVO_E_CAPACITY; }
+    mx = n > mx ? n : mx;
+  }
+  *max_n = mx;
+  // d_slot_base is free again after orb_run: reuse it to carry kp_base
+  MVO_HIP(hipMemcpyAsync(o->d_slot_base, hb, (size_t)(B + 1) * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  dim3 grid(std::max(1, (mx * 8 + 255) / 256), B);
+  hipLaunchKernelGGL(scatter_kp_kernel, grid, dim3(256), 0, ctx->stream, o->d_kp, o->d_desc, o->d_slot_base, ctx->maxpts,
+                     m->d_t, m->d_nt, p->d_kp_xy);
+  return MVO_OK;
+}
+
+// key-frame := current frame (descriptors, key-point positions); tracks := all current key-points.
+static int pipe_promote_keyframe(mvo_ctx* ctx, int max_n) {
+  PipeState* p = ctx->pipe;
+  MatchState* m = ctx->match;
+  std::swap(m->d_q, m->d_t);
+  std::swap(m->d_nq, m->d_nt);
+  std::swap(p->d_kfkp_xy, p->d_kp_xy);
+  p->kf_max_n = p->trk_max_n = max_n;
+  size_t np = (size_t)ctx->B * ctx->maxpts;
+  MVO_HIP(hipMemcpyAsync(ctx->d_prev_pts, p->d_kfkp_xy, np * 2 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+  MVO_HIP(hipMemcpyAsync(p->d_kf_pts, p->d_kfkp_xy, np * 2 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+  MVO_HIP(hipMemcpyAsync(ctx->d_npts, m->d_nq, (size_t)ctx->B * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+  return MVO_OK;
+}
+
+extern "C" int mvo_batch_seed(mvo_ctx* ctx, int frame_idx, int* n_keypoints) {
+  if (!ctx || !ctx->pipe) return MVO_E_ARG;
+  PipeState* p = ctx->pipe;
+  if (p->ring <= 0 || p->w == 0 || frame_idx < 0 || frame_idx >= p->ring) return MVO_E_ARG;
+  int rc;
+  LkLevels L = lk_levels(p->w, p->h, ctx->cfg.lk_win, ctx->cfg.lk_max_level);
+  ctx->lk_cur = 0;
+  if ((rc = pipe_load_frame(ctx, frame_idx, ctx->lk_cur))) return rc;
+  lk_build_pyramid(ctx, ctx->lk_cur, L, ctx->B);
+  std::vector<int> base;
+  if ((rc = orb_run(ctx, p->w, p->h, ctx->B, true, base))) return rc;
+  int mx = 0;
+  if ((rc = pipe_publish_orb(ctx, base, &mx))) return rc;
+  if ((rc = pipe_promote_keyframe(ctx, mx))) return rc;
+  MVO_HIP(hipStreamSynchronize(ctx->stream));
+  if (n_keypoints)
+    for (int s = 0; s < ctx->B; s++) n_keypoints[s] = base[s + 1] - base[s];
+  p->seeded = true;
+  return MVO_OK;
+}
+
+extern "C" int mvo_batch_get_tracks(mvo_ctx* ctx, int slot, float* pts, int cap, int* n) {
+  if (!ctx || !ctx->pipe || !n || slot < 0 || slot >= ctx->B) return MVO_E_ARG;
+  int cnt = 0;
+  MVO_HIP(hipMemcpyAsync(&cnt, ctx->d_npts + slot, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  MVO_HIP(hipStreamSynchronize(ctx->stream));
+  *n = cnt;
+  int m = cnt < cap ? cnt : cap;
+  if (m > 0 && pts) {
+    MVO_HIP(hipMemcpyAsync(pts, ctx->d_prev_pts + (size_t)slot * ctx->maxpts * 2, (size_t)m * 2 * sizeof(float),
+                           hipMemcpyDeviceToHost, ctx->stream));
+    MVO_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return MVO_OK;
+}
+
+extern "C" int mvo_batch_set_landmarks(mvo_ctx* ctx, int slot, const float* xyz, int n) {
+  if (!ctx || !ctx->pipe || !xyz || slot < 0 || slot >= ctx->B || n < 0 || n > ctx->maxpts) return MVO_E_ARG;
+  MVO_HIP(hipMemcpyAsync(ctx->pipe->d_lm + (size_t)slot * ctx->maxpts * 3, xyz, (size_t)n * 3 * sizeof(float),
+                         hipMemcpyHostToDevice, ctx->stream));
+  MVO_HIP(hipStreamSynchronize(ctx->stream));
+  return MVO_OK;
+}
+
+extern "C" int mvo_batch_step(mvo_ctx* ctx, int frame_idx, unsigned stages, mvo_step_result* out) {
+  if (!ctx || !ctx->pipe || !out) return MVO_E_ARG;
+  PipeState* p = ctx->pipe;
+  MatchState* m = ctx->match;
+  if (!p->seeded || frame_idx < 0 || frame_idx >= p->ring) { ctx->set_error("mvo_batch_step: not seeded / bad frame"); return MVO_E_ARG; }
+  const int B = ctx->B;
+  int rc;
+  LkLevels L = lk_levels(p->w, p->h, ctx->cfg.lk_win, ctx->cfg.lk_max_level);
+  const int prev_set = ctx->lk_cur, cur_set = ctx->lk_cur ^ 1;
+  memset(out, 0, sizeof(mvo_step_result) * B);
+  if ((rc = pipe_load_frame(ctx, frame_idx, cur_set))) return rc;
+  { ProfScope ps(ctx, "lk_pyramid"); lk_build_pyramid(ctx, cur_set, L, B); }
+  int* hb = p->h_ints + 4 * B;  // [0,B): n_prev, [B,2B): n_tracked, [2B,3B): n_matches
+  if (stages & MVO_STAGE_LK) {
+    { ProfScope ps(ctx, "lk_track"); lk_track_device(ctx, prev_set, cur_set, L, B, p->trk_max_n); }
+    ProfScope ps(ctx, "lk_filter");
+    hipLaunchKernelGGL(lk_filter_compact_kernel, dim3(B), dim3(1024), 0, ctx->stream, ctx->d_next_pts, ctx->d_status, ctx->d_err,
+                       ctx->d_npts, p->d_lm, p->d_kf_pts, ctx->cfg.tracking_error_thresh, ctx->maxpts, p->d_cur_pts,
+                       p->d_cur_lm, p->d_cur_kf, p->d_ncur);
+    MVO_HIP(hipMemcpyAsync(hb, ctx->d_npts, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MVO_HIP(hipMemcpyAsync(hb + B, p->d_ncur, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  int rc2 = pipe_geometry_stages(ctx, stages, out);
+  if (rc2) return rc2;
+  std::vector<int> base;
+  if (stages & MVO_STAGE_ORB) {
+    if ((rc = orb_run(ctx, p->w, p->h, B, true, base))) return rc;
+    int mx = 0;
+    if ((rc = pipe_publish_orb(ctx, base, &mx))) return rc;
+    if (stages & MVO_STAGE_MATCH) {
+      ProfScope ps(ctx, "match");
+      match_device(ctx, B, p->kf_max_n, ctx->cfg.lowes_distance_ratio);
+      MVO_HIP(hipMemcpyAsync(hb + 2 * B, m->d_nout, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if ((rc = pipe_promote_keyframe(ctx, mx))) return rc;
+  } else if (stages & MVO_STAGE_LK) {
+    // no key-frame: survivors become the next frame's tracks (src/tracker.cpp:331)
+    size_t np = (size_t)B * ctx->maxpts;
+    MVO_HIP(hipMemcpyAsync(ctx->d_prev_pts, p->d_cur_pts, np * 2 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    MVO_HIP(hipMemcpyAsync(p->d_lm, p->d_cur_lm, np * 3 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    MVO_HIP(hipMemcpyAsync(p->d_kf_pts, p->d_cur_kf, np * 2 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    MVO_HIP(hipMemcpyAsync(ctx->d_npts, p->d_ncur, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  MVO_HIP(hipStreamSynchronize(ctx->stream));
+  if ((stages & MVO_STAGE_LK) && !(stages & MVO_STAGE_ORB)) {
+    int mx = 0;
+    for (int s = 0; s < B; s++) mx = hb[B + s] > mx ? hb[B + s] : mx;
+    p->trk_max_n = mx;
+  }
+  for (int s = 0; s < B; s++) {
+    if (stages & MVO_STAGE_LK) { out[s].n_prev = hb[s]; out[s].n_tracked = hb[B + s]; }
+    if (stages & MVO_STAGE_ORB) out[s].n_keypoints = base[s + 1] - base[s];
+    if ((stages & MVO_STAGE_ORB) && (stages & MVO_STAGE_MATCH)) out[s].n_matches = hb[2 * B + s];
+  }
+  ctx->lk_cur = cur_set;
+  return MVO_OK;
+}
