@@ -26,6 +26,32 @@ int orc_orb_detect_and_compute(const unsigned char* img, int w, int h, int strid
 int orc_match_knn2_ratio(const unsigned char* q, int nq, const unsigned char* t, int nt, double ratio,
                          orc_match* out, int cap);
 
+int orc_find_homography_ransac(const float* p1, const float* p2, int n, double thr, int max_iters, double confidence,
+                               unsigned char* mask, double* H, int* stats);
+int orc_find_fundamental_ransac(const float* p1, const float* p2, int n, double thr, double confidence, int max_iters,
+                                unsigned char* mask, double* F, int* stats);
+int orc_h4_kernel(const float* p1, const float* p2, int n, double* H);
+int orc_f7_kernel(const float* p1, const float* p2, double* F);
+void orc_svd(const double* A, int m, int n, double* w, double* U, double* Vt, int full);
+void orc_eigen_sym(const double* A, int n, double* W, double* V);
+int orc_solve_cubic(const double* c, double* x);
+unsigned orc_rng_next(unsigned long long* state);
+int orc_ransac_update_num_iters(double p, double ep, int model_points, int max_iters);
+int orc_triangulate(const double* P1, const double* P2, const float* p1, const float* p2, int n, float* X3, float* X4);
+int orc_recover_pose(const double* E, const float* p1, const float* p2, int n, const double* K, double* R, double* t,
+                     unsigned char* mask_io);
+
+int orc_rodrigues_v2m(const double* r, double* R);
+int orc_rodrigues_m2v(const double* R, double* r);
+int orc_epnp(const float* obj, const float* img, int n, const double* K, double* rvec, double* tvec);
+int orc_solve_pnp_ransac(const float* obj, const float* img, int n, const double* K, const double* d, int iters,
+                         float reproj_err, double confidence, double* rvec, double* tvec, int* inlier_idx,
+                         int* n_inliers, int* stats);
+
+int orc_e5_kernel(const double* q1, const double* q2, int n, double* models);
+int orc_find_essential_ransac(const float* p1, const float* p2, int n, const double* K, double prob, double thr,
+                              int max_iters, unsigned char* mask, double* E, int* stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -123,3 +123,142 @@ def match_knn2_ratio(q, t, ratio=0.7):
     out = np.zeros(max(len(q), 1), MATCH_DTYPE)
     n = lib().orc_match_knn2_ratio(_p(q), len(q), _p(t), len(t), C.c_double(ratio), _p(out), len(out))
     return out[:n].copy()
+
+
+# ---- geometry ---------------------------------------------------------------------------------------
+def _f32(a, cols):
+    return np.ascontiguousarray(a, np.float32).reshape(-1, cols)
+
+
+def find_homography_ransac(p1, p2, thr=1.0, max_iters=2000, confidence=0.995):
+    p1, p2 = _f32(p1, 2), _f32(p2, 2)
+    n = len(p1)
+    mask = np.zeros(n, np.uint8); H = np.zeros(9); st = np.zeros(3, np.int32)
+    r = lib().orc_find_homography_ransac(_p(p1), _p(p2), n, C.c_double(thr), max_iters, C.c_double(confidence), _p(mask),
+                                         _p(H), _p(st))
+    return r, mask, H.reshape(3, 3), st
+
+
+def find_fundamental_ransac(p1, p2, thr=1.0, confidence=0.99, max_iters=1000):
+    p1, p2 = _f32(p1, 2), _f32(p2, 2)
+    n = len(p1)
+    mask = np.zeros(n, np.uint8); F = np.zeros(9); st = np.zeros(3, np.int32)
+    r = lib().orc_find_fundamental_ransac(_p(p1), _p(p2), n, C.c_double(thr), C.c_double(confidence), max_iters, _p(mask),
+                                          _p(F), _p(st))
+    return r, mask, F.reshape(3, 3), st
+
+
+def h4_kernel(p1, p2):
+    p1, p2 = _f32(p1, 2), _f32(p2, 2)
+    H = np.zeros(9)
+    r = lib().orc_h4_kernel(_p(p1), _p(p2), len(p1), _p(H))
+    return r, H.reshape(3, 3)
+
+
+def f7_kernel(p1, p2):
+    p1, p2 = _f32(p1, 2), _f32(p2, 2)
+    F = np.zeros(27)
+    r = lib().orc_f7_kernel(_p(p1), _p(p2), _p(F))
+    return r, F.reshape(3, 3, 3)[:max(r, 0)]
+
+
+def svd(A, full=False):
+    A = np.ascontiguousarray(A, np.float64)
+    m, n = A.shape
+    k = min(m, n)
+    w = np.zeros(k)
+    U = np.zeros((m, (max(m, n) if full else k) if m >= n else m))
+    Vt = np.zeros(((max(m, n) if full else k) if m < n else n, n))
+    lib().orc_svd(_p(A), m, n, _p(w), _p(U), _p(Vt), 1 if full else 0)
+    return U, w, Vt
+
+
+def eigen_sym(A):
+    A = np.ascontiguousarray(A, np.float64)
+    n = len(A)
+    W = np.zeros(n); V = np.zeros((n, n))
+    lib().orc_eigen_sym(_p(A), n, _p(W), _p(V))
+    return W, V
+
+
+def solve_cubic(c):
+    c = np.ascontiguousarray(c, np.float64)
+    x = np.zeros(3)
+    n = lib().orc_solve_cubic(_p(c), _p(x))
+    return n, x
+
+
+def rng_sequence(seed, count):
+    st = C.c_ulonglong(seed)
+    lib().orc_rng_next.restype = C.c_uint
+    return [lib().orc_rng_next(C.byref(st)) for _ in range(count)]
+
+
+def ransac_update_num_iters(p, ep, mp, mi):
+    return lib().orc_ransac_update_num_iters(C.c_double(p), C.c_double(ep), mp, mi)
+
+
+def triangulate(P1, P2, p1, p2):
+    P1 = np.ascontiguousarray(P1, np.float64).reshape(12); P2 = np.ascontiguousarray(P2, np.float64).reshape(12)
+    p1, p2 = _f32(p1, 2), _f32(p2, 2)
+    n = len(p1)
+    X3 = np.zeros((n, 3), np.float32); X4 = np.zeros((n, 4), np.float32)
+    lib().orc_triangulate(_p(P1), _p(P2), _p(p1), _p(p2), n, _p(X3), _p(X4))
+    return X3, X4
+
+
+def recover_pose(E, p1, p2, K, mask=None):
+    E = np.ascontiguousarray(E, np.float64).reshape(9); K = np.ascontiguousarray(K, np.float64).reshape(9)
+    p1, p2 = _f32(p1, 2), _f32(p2, 2)
+    n = len(p1)
+    R = np.zeros(9); t = np.zeros(3)
+    m = None if mask is None else np.ascontiguousarray(mask, np.uint8).copy()
+    g = lib().orc_recover_pose(_p(E), _p(p1), _p(p2), n, _p(K), _p(R), _p(t), _p(m) if m is not None else None)
+    return g, R.reshape(3, 3), t, m
+
+
+def rodrigues(x):
+    x = np.ascontiguousarray(x, np.float64)
+    if x.size == 3:
+        R = np.zeros(9)
+        lib().orc_rodrigues_v2m(_p(x.reshape(3)), _p(R))
+        return R.reshape(3, 3)
+    r = np.zeros(3)
+    lib().orc_rodrigues_m2v(_p(x.reshape(9)), _p(r))
+    return r
+
+
+def epnp(obj, img, K):
+    obj, img = _f32(obj, 3), _f32(img, 2)
+    K = np.ascontiguousarray(K, np.float64).reshape(9)
+    r = np.zeros(3); t = np.zeros(3)
+    lib().orc_epnp(_p(obj), _p(img), len(obj), _p(K), _p(r), _p(t))
+    return r, t
+
+
+def solve_pnp_ransac(obj, img, K, d=None, iters=100, reproj=8.0, conf=0.99):
+    obj, img = _f32(obj, 3), _f32(img, 2)
+    K = np.ascontiguousarray(K, np.float64).reshape(9)
+    d = np.zeros(5) if d is None else np.ascontiguousarray(d, np.float64).reshape(5)
+    n = len(obj)
+    r = np.zeros(3); t = np.zeros(3); idx = np.zeros(max(n, 1), np.int32); ni = C.c_int(0); st = np.zeros(3, np.int32)
+    rc = lib().orc_solve_pnp_ransac(_p(obj), _p(img), n, _p(K), _p(d), iters, C.c_float(reproj), C.c_double(conf), _p(r),
+                                    _p(t), _p(idx), C.byref(ni), _p(st))
+    return rc, r, t, idx[:ni.value].copy(), st
+
+
+def e5_kernel(q1, q2):
+    q1 = np.ascontiguousarray(q1, np.float64).reshape(-1, 2); q2 = np.ascontiguousarray(q2, np.float64).reshape(-1, 2)
+    m = np.zeros(90)
+    n = lib().orc_e5_kernel(_p(q1), _p(q2), len(q1), _p(m))
+    return m.reshape(10, 3, 3)[:max(n, 0)]
+
+
+def find_essential_ransac(p1, p2, K, prob=0.99, thr=1.0, max_iters=1000):
+    p1, p2 = _f32(p1, 2), _f32(p2, 2)
+    K = np.ascontiguousarray(K, np.float64).reshape(9)
+    n = len(p1)
+    mask = np.zeros(n, np.uint8); E = np.zeros(9); st = np.zeros(3, np.int32)
+    r = lib().orc_find_essential_ransac(_p(p1), _p(p2), n, _p(K), C.c_double(prob), C.c_double(thr), max_iters, _p(mask),
+                                        _p(E), _p(st))
+    return r, mask, E.reshape(3, 3), st
