@@ -163,3 +163,81 @@ class Context:
         n = C.c_int(0)
         self._check(self._L.mvo_profile_read(self._h, name.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    # -- a5: H / F RANSAC -----------------------------------------------------------------------------------
+    @staticmethod
+    def _pts(a, cols):
+        return np.ascontiguousarray(a, np.float32).reshape(-1, cols)
+
+    def find_homography_ransac(self, p1, p2, thr=1.0, max_iters=2000, confidence=0.995):
+        """cv::findHomography(p1, p2, RANSAC, thr, mask). Returns (ok, mask, H, n_inliers)."""
+        p1, p2 = self._pts(p1, 2), self._pts(p2, 2)
+        n = len(p1)
+        mask = np.zeros(n, np.uint8)
+        H = np.zeros(9)
+        ni = C.c_int(0)
+        rc = self._check(self._L.mvo_find_homography_ransac(self._h, ptr(p1), ptr(p2), n, C.c_double(thr), int(max_iters),
+                                                            C.c_double(confidence), ptr(mask), ptr(H), C.byref(ni)),
+                         allow=(_lib.MVO_E_DEGENERATE,))
+        return rc == 0, mask, H.reshape(3, 3), ni.value
+
+    def find_fundamental_ransac(self, p1, p2, thr=1.0, confidence=0.99, max_iters=1000):
+        """cv::findFundamentalMat(p1, p2, FM_RANSAC, thr, confidence, mask)."""
+        p1, p2 = self._pts(p1, 2), self._pts(p2, 2)
+        n = len(p1)
+        mask = np.zeros(n, np.uint8)
+        F = np.zeros(9)
+        ni = C.c_int(0)
+        rc = self._check(self._L.mvo_find_fundamental_ransac(self._h, ptr(p1), ptr(p2), n, C.c_double(thr),
+                                                             C.c_double(confidence), int(max_iters), ptr(mask), ptr(F),
+                                                             C.byref(ni)), allow=(_lib.MVO_E_DEGENERATE,))
+        return rc == 0, mask, F.reshape(3, 3), ni.value
+
+    # -- a4: PnP -------------------------------------------------------------------------------------------
+    def solve_pnp_ransac(self, obj, img, K, d=None, iters=100, reproj=8.0, confidence=0.99):
+        """cv::solvePnPRansac(obj, img, K, d, rvec, tvec, false, iters, reproj, confidence, inliers)."""
+        obj, img = self._pts(obj, 3), self._pts(img, 2)
+        K = np.ascontiguousarray(K, np.float64).reshape(9)
+        d = np.zeros(5) if d is None else np.ascontiguousarray(d, np.float64).reshape(5)
+        n = len(obj)
+        r = np.zeros(3); t = np.zeros(3)
+        idx = np.zeros(max(n, 1), np.int32)
+        ni = C.c_int(0)
+        rc = self._check(self._L.mvo_solve_pnp_ransac(self._h, ptr(obj), ptr(img), n, ptr(K), ptr(d), int(iters),
+                                                      C.c_float(reproj), C.c_double(confidence), ptr(r), ptr(t), ptr(idx),
+                                                      C.byref(ni)), allow=(_lib.MVO_E_DEGENERATE,))
+        return rc == 0, r, t, idx[:ni.value].copy()
+
+    # -- a6 / a7 ----------------------------------------------------------------------------------------------
+    def find_essential_ransac(self, p1, p2, K, prob=0.99, thr=1.0, max_iters=1000):
+        p1, p2 = self._pts(p1, 2), self._pts(p2, 2)
+        K = np.ascontiguousarray(K, np.float64).reshape(9)
+        n = len(p1)
+        mask = np.zeros(n, np.uint8)
+        E = np.zeros(9)
+        ni = C.c_int(0)
+        rc = self._check(self._L.mvo_find_essential_ransac(self._h, ptr(p1), ptr(p2), n, ptr(K), C.c_double(prob),
+                                                           C.c_double(thr), int(max_iters), ptr(mask), ptr(E), C.byref(ni)),
+                         allow=(_lib.MVO_E_DEGENERATE,))
+        return rc == 0, mask, E.reshape(3, 3), ni.value
+
+    def recover_pose(self, E, p1, p2, K, mask=None):
+        p1, p2 = self._pts(p1, 2), self._pts(p2, 2)
+        E = np.ascontiguousarray(E, np.float64).reshape(9)
+        K = np.ascontiguousarray(K, np.float64).reshape(9)
+        n = len(p1)
+        R = np.zeros(9); t = np.zeros(3)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8).copy()
+        g = C.c_int(0)
+        self._check(self._L.mvo_recover_pose(self._h, ptr(E), ptr(p1), ptr(p2), n, ptr(K), ptr(R), ptr(t),
+                                             ptr(m) if m is not None else None, C.byref(g)))
+        return g.value, R.reshape(3, 3), t, m
+
+    def triangulate(self, P1, P2, p1, p2):
+        p1, p2 = self._pts(p1, 2), self._pts(p2, 2)
+        P1 = np.ascontiguousarray(P1, np.float64).reshape(12)
+        P2 = np.ascontiguousarray(P2, np.float64).reshape(12)
+        n = len(p1)
+        X3 = np.zeros((n, 3), np.float32)
+        self._check(self._L.mvo_triangulate(self._h, ptr(P1), ptr(P2), ptr(p1), ptr(p2), n, ptr(X3)))
+        return X3

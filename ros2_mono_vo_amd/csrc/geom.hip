@@ -1,7 +1,929 @@
-// csrc/geom.hip — placeholder translation unit (RANSAC / PnP / triangulation land here).
+// csrc/geom.hip — batched RANSAC engine and two-view / PnP geometry for gfx950.
+//
+// Replaces, with OpenCV-4.6 semantics:
+//   cv::findHomography(RANSAC) / cv::findFundamentalMat(FM_RANSAC)   reference src/tracker.cpp:243,248,
+//                                                                     src/initializer.cpp:82,87
+//   cv::solvePnPRansac + cv::Rodrigues                               reference src/tracker.cpp:309-316
+//   cv::triangulatePoints + convertPointsFromHomogeneous             reference src/tracker.cpp:149-152
+//   cv::recoverPose                                                  reference src/initializer.cpp:236
+//
+// ransac_kernel<Model>: ONE WORKGROUP PER PROBLEM (camera stream), so a batch of B streams is B
+// workgroups in one launch.  OpenCV's loop is sequential (adaptive iteration count, "strictly better"
+// update, data-dependent RNG consumption), so each round does
+//   1. lane 0 draws up to 64 candidate samples from cv::RNG((uint64)-1) in OpenCV's order,
+//   2. 64 lanes run checkSubset in parallel; an ordered ballot compaction turns passing candidates into
+//      RANSAC iterations (a failing candidate is exactly OpenCV's "retry with the next draws"),
+//   3. one hypothesis per lane: minimal solver (4-pt H / 7-pt F / 5-pt EPnP) in private memory,
+//   4. 256 lanes score: hypothesis = lane & 63, point quarter = lane >> 6; integer inlier counts,
+//   5. lane 0 replays the hypotheses in order applying the consensus update and RANSACUpdateNumIters,
+// and stops as soon as iter >= niters — the speculative tail of a round is simply discarded, which is
+// unobservable because nothing after the loop reads the RNG.  The consensus mask is then recomputed for
+// the winning model by all lanes.  No MFMA: nothing here is a dense contraction.
 #include "mvo_internal.h"
-struct GeomState { int dummy; };
-int geom_state_create(mvo_ctx* ctx) { ctx->geom = new GeomState(); return MVO_OK; }
-void geom_state_destroy(mvo_ctx* ctx) { delete ctx->geom; ctx->geom = nullptr; }
+#include "geom_models.h"
+
+#include <cstdlib>
+
+struct GeomState {
+  float* d_m1 = nullptr;   // [B][maxpts][3]
+  float* d_m2 = nullptr;   // [B][maxpts][2]
+  int* d_n = nullptr;      // [B]
+  u8* d_mask = nullptr;    // [B][maxpts]
+  double* d_model = nullptr;  // [B][16]
+  int* d_result = nullptr;    // [B][8]
+  // PnP refine
+  int* d_inl = nullptr;       // [B][maxpts] inlier indices
+  double* d_pose = nullptr;   // [B][8] rvec, tvec
+  float* d_x3 = nullptr;      // [B][maxpts][3]
+  // second set for running H and F side by side in the pipeline
+  u8* d_mask2 = nullptr;
+  double* d_model2 = nullptr;
+  int* d_result2 = nullptr;
+  double* d_tmp = nullptr;    // 64 doubles of scratch
+  double* h_model = nullptr;  // pinned
+  int* h_result = nullptr;
+};
+
+struct RansacArgs {
+  const float* m1;
+  const float* m2;
+  int stride1, stride2;  // floats between slots
+  const int* n;
+  double thr, conf;
+  int max_iters;
+  int cap;  // capacity per slot: counts are clamped to it so a corrupt count can never run away
+  ModelParams P;
+  u8* mask;
+  int mask_stride;
+  double* model;  // [B][16]
+  int* result;    // [B][8]: ok, n_inliers, iters_run, niters_final, models_scored
+};
+
+#define RS_CH 64
+#ifndef RS_WAVES_PER_EU
+#define RS_WAVES_PER_EU 1
+#endif
+
+template <class M>
+__global__ __launch_bounds__(256, RS_WAVES_PER_EU) void ransac_kernel(RansacArgs A) {
+  __shared__ int s_att[RS_CH][M::MP];
+  __shared__ int s_idx[RS_CH][M::MP];
+  __shared__ double s_models[RS_CH][M::MAXM][M::MS];
+  __shared__ int s_nmodels[RS_CH];
+  __shared__ int s_cnt[RS_CH][M::MAXM];
+  __shared__ double s_best[M::MS];
+  __shared__ int s_ctl[8];  // 0: npass, 1: done, 2: maxGood, 3: iter, 4: niters, 5: consec_fail, 6: ok, 7: models scored
+  __shared__ unsigned long long s_rng;
+
+  const int slot = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int count = min(max(A.n[slot], 0), A.cap);
+  const float* m1 = A.m1 + (size_t)slot * A.stride1;
+  const float* m2 = A.m2 + (size_t)slot * A.stride2;
+  u8* mask = A.mask + (size_t)slot * A.mask_stride;
+  double* out_model = A.model + (size_t)slot * 16;
+  int* result = A.result + (size_t)slot * 8;
+  const float t = (float)(A.thr * A.thr);
+
+  if (count < M::MP) {
+    for (int i = tid; i < count; i += 256) mask[i] = 0;
+    if (tid == 0) { result[0] = 0; result[1] = 0; result[2] = 0; result[3] = 0; result[4] = 0; }
+    return;
+  }
+  if (tid == 0) {
+    s_rng = 0xFFFFFFFFFFFFFFFFULL;
+    s_ctl[1] = 0; s_ctl[2] = 0; s_ctl[3] = 0; s_ctl[4] = A.max_iters > 1 ? A.max_iters : 1; s_ctl[5] = 0; s_ctl[6] = 0; s_ctl[7] = 0;
+  }
+  __syncthreads();
+
+  if (count == M::MP) {
+    // a single runKernel on all points, mask all ones
+    if (tid == 0) {
+      float ms1[M::MP * M::PT1], ms2[M::MP * M::PT2];
+      for (int i = 0; i < M::MP * M::PT1; i++) ms1[i] = m1[i];
+      for (int i = 0; i < M::MP * M::PT2; i++) ms2[i] = m2[i];
+      double models[M::MAXM * M::MS];
+      int nm = M::solve(A.P, ms1, ms2, models);
+      s_ctl[6] = nm > 0;
+      if (nm > 0)
+        for (int k = 0; k < M::MS; k++) out_model[k] = models[k];
+    }
+    __syncthreads();
+    int ok = s_ctl[6];
+    for (int i = tid; i < count; i += 256) mask[i] = ok ? 1 : 0;
+    if (tid == 0) { result[0] = ok; result[1] = ok ? count : 0; result[2] = 1; result[3] = 1; result[4] = 1; }
+    return;
+  }
+
+  for (;;) {
+    // ---- 1. candidate samples, OpenCV's getSubset draw order ------------------------------------------
+    if (tid == 0) {
+      GlRng rng(s_rng);
+      for (int a = 0; a < RS_CH; a++) {
+        for (int i = 0; i < M::MP; ++i) {
+          int idx_i;
+          for (;;) {
+            idx_i = rng.uniform(0, count);
+            bool dup = false;
+            for (int k = 0; k < i; k++) dup |= (s_att[a][k] == idx_i);
+            if (!dup) break;
+          }
+          s_att[a][i] = idx_i;
+        }
+      }
+      s_rng = rng.state;
+    }
+    __syncthreads();
+    // ---- 2. checkSubset in parallel + ordered compaction --------------------------------------------------
+    if (wave == 0) {
+      float ms1[M::MP * M::PT1], ms2[M::MP * M::PT2];
+      for (int i = 0; i < M::MP; i++) {
+        int id = s_att[lane][i];
+        for (int k = 0; k < M::PT1; k++) ms1[i * M::PT1 + k] = m1[(size_t)id * M::PT1 + k];
+        for (int k = 0; k < M::PT2; k++) ms2[i * M::PT2 + k] = m2[(size_t)id * M::PT2 + k];
+      }
+      bool pass = M::check_subset(ms1, ms2);
+      unsigned long long bm = __ballot(pass);
+      int pos = __popcll(bm & ((1ull << lane) - 1));
+      if (pass)
+        for (int i = 0; i < M::MP; i++) s_idx[pos][i] = s_att[lane][i];
+      if (lane == 0) {
+        int np = __popcll(bm);
+        s_ctl[0] = np;
+        // OpenCV gives up on an iteration after 10000 consecutive failing attempts
+        int tail = bm ? __clzll(bm) : 64;  // failing attempts after the last pass
+        int run = s_ctl[5];
+        bool abort_ = false;
+        if (np == 0) { run += 64; abort_ = run >= 10000; }
+        else {
+          int lead = __ffsll((long long)bm) - 1;  // failing attempts before the first pass
+          abort_ = (run + lead) >= 10000;
+          run = tail;
+        }
+        s_ctl[5] = run;
+        if (abort_) s_ctl[1] = 1;
+      }
+    }
+    __syncthreads();
+    if (s_ctl[1]) break;
+    const int npass = s_ctl[0];
+    // ---- 3. minimal solver, one hypothesis per lane ---------------------------------------------------------
+    if (tid < RS_CH) {
+      s_nmodels[tid] = 0;
+      for (int k = 0; k < M::MAXM; k++) s_cnt[tid][k] = 0;
+    }
+    __syncthreads();
+    if (wave == 0 && lane < npass) {
+      float ms1[M::MP * M::PT1], ms2[M::MP * M::PT2];
+      for (int i = 0; i < M::MP; i++) {
+        int id = s_idx[lane][i];
+        for (int k = 0; k < M::PT1; k++) ms1[i * M::PT1 + k] = m1[(size_t)id * M::PT1 + k];
+        for (int k = 0; k < M::PT2; k++) ms2[i * M::PT2 + k] = m2[(size_t)id * M::PT2 + k];
+      }
+      double models[M::MAXM * M::MS];
+      int nm = M::solve(A.P, ms1, ms2, models);
+      if (nm < 0) nm = 0;
+      if (nm > M::MAXM) nm = M::MAXM;
+      s_nmodels[lane] = nm;
+      for (int q = 0; q < nm; q++)
+        for (int k = 0; k < M::MS; k++) s_models[lane][q][k] = models[q * M::MS + k];
+    }
+    __syncthreads();
+    // ---- 4. scoring: hypothesis = lane, point quarter = wave ---------------------------------------------
+    if (lane < npass) {
+      int nm = s_nmodels[lane];
+      for (int q = 0; q < nm; q++) {
+        typename M::Scorer sc;
+        sc.init(A.P, &s_models[lane][q][0]);
+        int good = 0;
+        for (int i = wave; i < count; i += 4) good += sc.err(m1 + (size_t)i * M::PT1, m2 + (size_t)i * M::PT2) <= t;
+        atomicAdd(&s_cnt[lane][q], good);
+      }
+    }
+    __syncthreads();
+    // ---- 5. ordered replay of OpenCV's consensus update -------------------------------------------------------
+    if (tid == 0) {
+      int maxGood = s_ctl[2], iter = s_ctl[3], niters = s_ctl[4], scored = s_ctl[7];
+      for (int h = 0; h < npass && iter < niters; h++, iter++) {
+        int nm = s_nmodels[h];
+        for (int q = 0; q < nm; q++) {
+          int good = s_cnt[h][q];
+          scored++;
+          if (good > max(maxGood, M::MP - 1)) {
+            for (int k = 0; k < M::MS; k++) s_best[k] = s_models[h][q][k];
+            maxGood = good;
+            niters = gl_ransac_update_num_iters(A.conf, (double)(count - good) / count, M::MP, niters);
+          }
+        }
+      }
+      s_ctl[2] = maxGood; s_ctl[3] = iter; s_ctl[4] = niters; s_ctl[7] = scored;
+      if (iter >= niters) s_ctl[1] = 1;
+    }
+    __syncthreads();
+    if (s_ctl[1]) break;
+  }
+  // ---- consensus mask of the winning model ---------------------------------------------------------------------
+  const int maxGood = s_ctl[2];
+  if (maxGood > 0) {
+    typename M::Scorer sc;
+    sc.init(A.P, s_best);
+    for (int i = tid; i < count; i += 256) mask[i] = sc.err(m1 + (size_t)i * M::PT1, m2 + (size_t)i * M::PT2) <= t ? 1 : 0;
+    if (tid < M::MS) out_model[tid] = s_best[tid];
+  } else {
+    for (int i = tid; i < count; i += 256) mask[i] = 0;
+  }
+  if (tid == 0) { result[0] = maxGood > 0; result[1] = maxGood; result[2] = s_ctl[3]; result[3] = s_ctl[4]; result[4] = s_ctl[7]; }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// PnP: consensus set -> ordered inlier list; then cvFindExtrinsicCameraParams2 (DLT / planar init + LM)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void mask_to_indices_kernel(const u8* __restrict__ mask, int mask_stride, const int* __restrict__ n_,
+                                                               int* __restrict__ idx, int idx_stride, int* __restrict__ result) {
+  __shared__ int s_wave[16];
+  __shared__ int s_base;
+  const int slot = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = min(max(n_[slot], 0), mask_stride);
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += 1024) {
+    int i = i0 + threadIdx.x;
+    bool keep = i < n && mask[(size_t)slot * mask_stride + i];
+    unsigned long long m = __ballot(keep);
+    int pre = __popcll(m & ((1ull << lane) - 1));
+    if (lane == 0) s_wave[wave] = __popcll(m);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wave; w++) off += s_wave[w];
+    if (keep) idx[(size_t)slot * idx_stride + off + pre] = i;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int w = 0; w < 16; w++) t += s_wave[w];
+      s_base += t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) result[(size_t)slot * 8 + 5] = s_base;
+}
+
+#define PR_T 256
+// deterministic block-wide sum of `K` doubles per thread (tree over LDS, fixed order)
+template <int K>
+__device__ inline void block_sum(double* v, double* s_red /* [PR_T] */, double* out /* [K], valid in all threads */) {
+  for (int k = 0; k < K; k++) {
+    s_red[threadIdx.x] = v[k];
+    __syncthreads();
+    for (int s = PR_T / 2; s > 0; s >>= 1) {
+      if (threadIdx.x < s) s_red[threadIdx.x] += s_red[threadIdx.x + s];
+      __syncthreads();
+    }
+    out[k] = s_red[0];
+    __syncthreads();
+  }
+}
+
+struct PnpRefineArgs {
+  const float* obj;  // [B][maxpts][3]
+  const float* img;  // [B][maxpts][2]
+  int stride_pts;    // points between slots
+  const int* inl;    // [B][maxpts]
+  int* result;       // [B][8]: [0] ransac ok, [5] n inliers -> [6] refine status
+  const double* model;  // [B][16] RANSAC model (3x2 hconcat)
+  const int* n;         // [B] correspondences per slot
+  double* pose;      // [B][8]
+  CamK cam;
+};
+
+// One workgroup per stream.  Sums over the inlier set are block reductions in a fixed order (the oracle
+// sums sequentially, so R,t agree to rounding, not bit for bit); the small dense solves run on lane 0.
+__global__ __launch_bounds__(PR_T) void pnp_refine_kernel(PnpRefineArgs A) {
+  __shared__ double s_red[PR_T];
+  __shared__ double s_sh[160];  // broadcast area
+  __shared__ int s_flag[4];
+  const int slot = blockIdx.x, tid = threadIdx.x;
+  int* result = A.result + (size_t)slot * 8;
+  double* pose = A.pose + (size_t)slot * 8;
+  const int ok = result[0];
+  const int count = min(max(result[5], 0), A.stride_pts);
+  if (!ok) { if (tid == 0) result[6] = 0; return; }
+  if (A.n[slot] == 5) {
+    // solvePnPRansac with exactly model_points correspondences returns the EPnP solution as is
+    if (tid == 0) {
+      const double* model = A.model + (size_t)slot * 16;
+      for (int i = 0; i < 3; i++) { pose[i] = model[2 * i]; pose[3 + i] = model[2 * i + 1]; }
+      result[6] = 1;
+    }
+    return;
+  }
+  const float* obj = A.obj + (size_t)slot * A.stride_pts * 3;
+  const float* img = A.img + (size_t)slot * A.stride_pts * 2;
+  const int* inl = A.inl + (size_t)slot * A.stride_pts;
+  const CamK cam = A.cam;
+  const double ifx = 1. / cam.fx, ify = 1. / cam.fy;
+  auto ptM = [&](int i, double M[3]) { int id = inl[i]; M[0] = obj[3 * id]; M[1] = obj[3 * id + 1]; M[2] = obj[3 * id + 2]; };
+  auto ptm = [&](int i, double m[2]) { int id = inl[i]; m[0] = img[2 * id]; m[1] = img[2 * id + 1]; };
+
+  double param[6] = {0, 0, 0, 0, 0, 0};
+  // ---- Mc, MM ------------------------------------------------------------------------------------------------
+  double acc[78];
+  double Mc[3];
+  {
+    double v[3] = {0, 0, 0};
+    for (int i = tid; i < count; i += PR_T) { double M[3]; ptM(i, M); v[0] += M[0]; v[1] += M[1]; v[2] += M[2]; }
+    block_sum<3>(v, s_red, Mc);
+    for (int j = 0; j < 3; j++) Mc[j] /= count;
+  }
+  double MM[9];
+  {
+    double v[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = tid; i < count; i += PR_T) {
+      double M[3]; ptM(i, M);
+      double d0 = M[0] - Mc[0], d1 = M[1] - Mc[1], d2 = M[2] - Mc[2];
+      v[0] += d0 * d0; v[1] += d0 * d1; v[2] += d0 * d2; v[3] += d1 * d1; v[4] += d1 * d2; v[5] += d2 * d2;
+    }
+    double o[6];
+    block_sum<6>(v, s_red, o);
+    MM[0] = o[0]; MM[1] = MM[3] = o[1]; MM[2] = MM[6] = o[2]; MM[4] = o[3]; MM[5] = MM[7] = o[4]; MM[8] = o[5];
+  }
+  // lane 0: planarity test (3x3 SVD), broadcast Vt and the flag
+  if (tid == 0) {
+    double W[3], V[9];
+    gl_svd3(MM, W, nullptr, V);
+    bool planar = W[2] / W[1] < 1e-3;
+    s_flag[0] = planar;
+    if (planar) {
+      if (V[2] * V[2] + V[5] * V[5] < 1e-10) { for (int i = 0; i < 9; i++) V[i] = (i % 4 == 0) ? 1 : 0; }
+      if (gl_det3(V) < 0) for (int i = 0; i < 9; i++) V[i] *= -1;
+    }
+    for (int i = 0; i < 9; i++) s_sh[i] = V[i];
+  }
+  __syncthreads();
+  const bool planar = s_flag[0];
+  if (planar) {
+    double Rt[9], tt[3];
+    for (int i = 0; i < 9; i++) Rt[i] = s_sh[i];
+    for (int r = 0; r < 3; r++) tt[r] = -(Rt[r * 3] * Mc[0] + Rt[r * 3 + 1] * Mc[1] + Rt[r * 3 + 2] * Mc[2]);
+    __syncthreads();
+    auto mxy = [&](int i, double& X, double& Y) {
+      double M[3]; ptM(i, M);
+      X = Rt[0] * M[0] + Rt[1] * M[1] + Rt[2] * M[2] + tt[0];
+      Y = Rt[3] * M[0] + Rt[4] * M[1] + Rt[5] * M[2] + tt[1];
+    };
+    auto mnorm = [&](int i, double& x, double& y) { double m[2]; ptm(i, m); x = (m[0] - cam.cx) * ifx; y = (m[1] - cam.cy) * ify; };
+    // normalised DLT homography Mxy -> mn (HomographyEstimatorCallback::runKernel on all points)
+    double c4[4];
+    {
+      double v[4] = {0, 0, 0, 0};
+      for (int i = tid; i < count; i += PR_T) { double X, Y, x, y; mxy(i, X, Y); mnorm(i, x, y); v[0] += x; v[1] += y; v[2] += X; v[3] += Y; }
+      block_sum<4>(v, s_red, c4);
+      for (int k = 0; k < 4; k++) c4[k] /= count;
+    }
+    double s4[4];
+    {
+      double v[4] = {0, 0, 0, 0};
+      for (int i = tid; i < count; i += PR_T) {
+        double X, Y, x, y; mxy(i, X, Y); mnorm(i, x, y);
+        v[0] += fabs(x - c4[0]); v[1] += fabs(y - c4[1]); v[2] += fabs(X - c4[2]); v[3] += fabs(Y - c4[3]);
+      }
+      block_sum<4>(v, s_red, s4);
+    }
+    bool degenerate = fabs(s4[0]) < DBL_EPSILON || fabs(s4[1]) < DBL_EPSILON || fabs(s4[2]) < DBL_EPSILON || fabs(s4[3]) < DBL_EPSILON;
+    double smx = count / s4[0], smy = count / s4[1], sMx = count / s4[2], sMy = count / s4[3];
+    double LtL[45];
+    {
+      for (int k = 0; k < 45; k++) acc[k] = 0;
+      if (!degenerate)
+        for (int i = tid; i < count; i += PR_T) {
+          double X, Y, x, y; mxy(i, X, Y); mnorm(i, x, y);
+          x = (x - c4[0]) * smx; y = (y - c4[1]) * smy; X = (X - c4[2]) * sMx; Y = (Y - c4[3]) * sMy;
+          double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
+          double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
+          int q = 0;
+          for (int j = 0; j < 9; j++)
+            for (int k = j; k < 9; k++) acc[q++] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
+        }
+      block_sum<45>(acc, s_red, LtL);
+    }
+    if (tid == 0) {
+      double R[9];
+      bool okH = !degenerate;
+      double h[9];
+      if (okH) {
+        double L[81], W[9], V[81];
+        int q = 0;
+        for (int j = 0; j < 9; j++)
+          for (int k = j; k < 9; k++) { L[j * 9 + k] = LtL[q]; L[k * 9 + j] = LtL[q]; q++; }
+        gl_jacobi_eigen(L, 9, W, V);
+        double invHnorm[9] = {1. / smx, 0, c4[0], 0, 1. / smy, c4[1], 0, 0, 1};
+        double Hnorm2[9] = {sMx, 0, -c4[2] * sMx, 0, sMy, -c4[3] * sMy, 0, 0, 1};
+        double Htemp[9], H0[9];
+        gl_mat3mul(invHnorm, V + 72, Htemp);
+        gl_mat3mul(Htemp, Hnorm2, H0);
+        double s = 1. / H0[8];
+        for (int i = 0; i < 9; i++) { h[i] = H0[i] * s; okH = okH && isfinite(h[i]); }
+      }
+      if (okH) {
+        double h1_norm = sqrt(h[0] * h[0] + h[3] * h[3] + h[6] * h[6]);
+        double h2_norm = sqrt(h[1] * h[1] + h[4] * h[4] + h[7] * h[7]);
+        double s1 = 1. / fmax(h1_norm, DBL_EPSILON), s2 = 1. / fmax(h2_norm, DBL_EPSILON);
+        double s3 = 2. / fmax(h1_norm + h2_norm, DBL_EPSILON);
+        double t[3] = {h[2] * s3, h[5] * s3, h[8] * s3};
+        h[0] *= s1; h[3] *= s1; h[6] *= s1;
+        h[1] *= s2; h[4] *= s2; h[7] *= s2;
+        h[2] = h[3] * h[7] - h[6] * h[4];
+        h[5] = h[6] * h[1] - h[0] * h[7];
+        h[8] = h[0] * h[4] - h[3] * h[1];
+        double r[3], Hm[9];
+        gm_rodrigues_m2v(h, r);
+        gm_rodrigues_v2m(r, Hm, nullptr);
+        for (int k = 0; k < 3; k++) param[3 + k] = Hm[k * 3] * tt[0] + Hm[k * 3 + 1] * tt[1] + Hm[k * 3 + 2] * tt[2] + t[k];
+        gl_mat3mul(Hm, Rt, R);
+      } else {
+        for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1 : 0;
+        param[3] = param[4] = param[5] = 0;
+      }
+      gm_rodrigues_m2v(R, param);
+      for (int i = 0; i < 6; i++) s_sh[i] = param[i];
+      s_flag[1] = 1;
+    }
+    __syncthreads();
+  } else {
+    if (count < 6) {
+      // "DLT algorithm needs at least 6 points": with exactly 5 inliers OpenCV keeps the minimal-sample model
+      if (tid == 0) {
+        const double* model = A.model + (size_t)slot * 16;
+        if (count == 5) {
+          for (int i = 0; i < 3; i++) { pose[i] = model[2 * i]; pose[3 + i] = model[2 * i + 1]; }
+          result[6] = 1;
+        } else {
+          result[6] = 0;
+        }
+      }
+      return;
+    }
+    double LL[78];
+    for (int k = 0; k < 78; k++) acc[k] = 0;
+    for (int i = tid; i < count; i += PR_T) {
+      double M[3], m[2]; ptM(i, M); ptm(i, m);
+      double x = -((m[0] - cam.cx) * ifx), y = -((m[1] - cam.cy) * ify);
+      double l0[12] = {M[0], M[1], M[2], 1., 0, 0, 0, 0, x * M[0], x * M[1], x * M[2], x};
+      double l1[12] = {0, 0, 0, 0, M[0], M[1], M[2], 1., y * M[0], y * M[1], y * M[2], y};
+      int q = 0;
+      for (int a = 0; a < 12; a++)
+        for (int b = a; b < 12; b++) acc[q++] += l0[a] * l0[b] + l1[a] * l1[b];
+    }
+    block_sum<78>(acc, s_red, LL);
+    if (tid == 0) {
+      double L[144], LW[12], LV[144];
+      int q = 0;
+      for (int a = 0; a < 12; a++)
+        for (int b = a; b < 12; b++) { L[a * 12 + b] = LL[q]; L[b * 12 + a] = LL[q]; q++; }
+      // cvSVD(&_LL, &_LW, 0, &_LV, MODIFY_A + V_T): Vt; run the one-sided Jacobi on L^T (= L)
+      gl_jacobi_svd(L, 12, LW, LV, 12, 12, 12);
+      double* RRt = LV + 11 * 12;
+      double RR[9], ttv[3];
+      for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) RR[r * 3 + c] = RRt[r * 4 + c]; ttv[r] = RRt[r * 4 + 3]; }
+      if (gl_det3(RR) < 0) { for (int i = 0; i < 9; i++) RR[i] *= -1; for (int i = 0; i < 3; i++) ttv[i] *= -1; }
+      double sc = 0;
+      for (int i = 0; i < 9; i++) sc += RR[i] * RR[i];
+      sc = sqrt(sc);
+      int good = fabs(sc) > DBL_EPSILON;
+      if (good) {
+        double Wd[3], U[9], Vt[9], R[9];
+        gl_svd3(RR, Wd, U, Vt);
+        gl_mat3mul(U, Vt, R);
+        double nR = 0;
+        for (int i = 0; i < 9; i++) nR += R[i] * R[i];
+        nR = sqrt(nR);
+        for (int k = 0; k < 3; k++) param[3 + k] = ttv[k] * (nR / sc);
+        gm_rodrigues_m2v(R, param);
+      }
+      for (int i = 0; i < 6; i++) s_sh[i] = param[i];
+      s_flag[1] = good;
+    }
+    __syncthreads();
+  }
+  if (!s_flag[1]) { if (tid == 0) result[6] = 0; return; }
+  for (int i = 0; i < 6; i++) param[i] = s_sh[i];
+  __syncthreads();
+
+  // ---- CvLevMarq (J + err mode), state machine replicated by every lane, solves on lane 0 --------------------
+  enum { DONE = 0, STARTED = 1, CALC_J = 2, CHECK_ERR = 3 };
+  int state = STARTED, iters = 0, lambdaLg10 = -3;
+  double prevParam[6], JtJ[21], JtErr[6], prevErrNorm = DBL_MAX, errNorm = 0, curErr2 = 0;
+  const int max_iter = 20;
+  const double epsilon = FLT_EPSILON;
+  auto step = [&]() {
+    if (tid == 0) {
+      const double LOG10 = log(10.);
+      double lambda = exp(lambdaLg10 * LOG10);
+      double Am[36], x[6];
+      int q = 0;
+      for (int a = 0; a < 6; a++)
+        for (int b = a; b < 6; b++) { Am[a * 6 + b] = JtJ[q]; Am[b * 6 + a] = JtJ[q]; q++; }
+      for (int i = 0; i < 6; i++) Am[i * 6 + i] *= 1. + lambda;
+      gl_solve_svd(Am, 6, 6, JtErr, x);
+      for (int i = 0; i < 6; i++) s_sh[i] = prevParam[i] - x[i];
+    }
+    __syncthreads();
+    for (int i = 0; i < 6; i++) param[i] = s_sh[i];
+    __syncthreads();
+  };
+  auto eval = [&](bool withJ) {
+    double R[9], dRdr[27];
+    gm_rodrigues_v2m(param, R, withJ ? dRdr : nullptr);
+    double v[28];
+    for (int k = 0; k < 28; k++) v[k] = 0;
+    for (int i = tid; i < count; i += PR_T) {
+      double M[3], m[2], mm[2], dpdr[6], dpdt[6];
+      ptM(i, M); ptm(i, m);
+      gm_project_point(R, withJ ? dRdr : nullptr, param + 3, cam, M, mm, withJ ? dpdr : nullptr, withJ ? dpdt : nullptr);
+      double e0 = mm[0] - m[0], e1 = mm[1] - m[1];
+      v[27] += e0 * e0 + e1 * e1;
+      if (withJ) {
+        double j0[6] = {dpdr[0], dpdr[1], dpdr[2], dpdt[0], dpdt[1], dpdt[2]};
+        double j1[6] = {dpdr[3], dpdr[4], dpdr[5], dpdt[3], dpdt[4], dpdt[5]};
+        int q = 0;
+        for (int a = 0; a < 6; a++)
+          for (int b = a; b < 6; b++) v[q++] += j0[a] * j0[b] + j1[a] * j1[b];
+        for (int a = 0; a < 6; a++) v[21 + a] += j0[a] * e0 + j1[a] * e1;
+      }
+    }
+    double o[28];
+    if (withJ) {
+      block_sum<28>(v, s_red, o);
+      for (int k = 0; k < 21; k++) JtJ[k] = o[k];
+      for (int k = 0; k < 6; k++) JtErr[k] = o[21 + k];
+      curErr2 = o[27];
+    } else {
+      block_sum<1>(v + 27, s_red, o);
+      curErr2 = o[0];
+    }
+  };
+  for (;;) {
+    bool wantJ = false, wantErr = false, proceed;
+    if (state == DONE) { proceed = false; }
+    else if (state == STARTED) { wantJ = wantErr = true; state = CALC_J; proceed = true; }
+    else if (state == CALC_J) {
+      for (int i = 0; i < 6; i++) prevParam[i] = param[i];
+      double errAtJ = sqrt(curErr2);
+      step();
+      if (iters == 0) prevErrNorm = errAtJ;
+      wantErr = true;
+      state = CHECK_ERR;
+      proceed = true;
+    } else {
+      errNorm = sqrt(curErr2);
+      bool handled = false;
+      if (errNorm > prevErrNorm) {
+        if (++lambdaLg10 <= 16) {
+          step();
+          wantErr = true;
+          state = CHECK_ERR;
+          proceed = true;
+          handled = true;
+        }
+      }
+      if (!handled) {
+        lambdaLg10 = lambdaLg10 - 1 > -16 ? lambdaLg10 - 1 : -16;
+        double dn = 0, pn = 0;
+        for (int i = 0; i < 6; i++) { dn += (param[i] - prevParam[i]) * (param[i] - prevParam[i]); pn += prevParam[i] * prevParam[i]; }
+        double rel = sqrt(dn) / (sqrt(pn) + DBL_EPSILON);
+        if (++iters >= max_iter || rel < epsilon) { state = DONE; proceed = true; }
+        else { prevErrNorm = errNorm; wantJ = wantErr = true; state = CALC_J; proceed = true; }
+      }
+    }
+    if (!proceed || !wantErr) break;
+    eval(wantJ);
+  }
+  if (tid == 0) {
+    for (int i = 0; i < 6; i++) pose[i] = param[i];
+    result[6] = 1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// triangulation (one point per lane) and recoverPose
+// ---------------------------------------------------------------------------------------------------
+__device__ inline void gm_triangulate_one(const double* P1, const double* P2, double x1, double y1, double x2, double y2, double X[4]) {
+  double A[16], w[4], vt[16], ta[16], tv[16];
+  for (int k = 0; k < 4; k++) {
+    A[0 * 4 + k] = x1 * P1[8 + k] - P1[0 + k];
+    A[1 * 4 + k] = y1 * P1[8 + k] - P1[4 + k];
+    A[2 * 4 + k] = x2 * P2[8 + k] - P2[0 + k];
+    A[3 * 4 + k] = y2 * P2[8 + k] - P2[4 + k];
+  }
+  gl_svd_compute(A, 4, 4, w, nullptr, vt, false, ta, tv);
+  for (int k = 0; k < 4; k++) X[k] = vt[12 + k];
+}
+
+struct Proj2 { double P1[12], P2[12]; };
+
+__global__ __launch_bounds__(256) void triangulate_kernel(Proj2 P, const float* __restrict__ p1, const float* __restrict__ p2, int n,
+                                                          float* __restrict__ X3) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double X[4];
+  gm_triangulate_one(P.P1, P.P2, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1], X);
+  float xf[4] = {(float)X[0], (float)X[1], (float)X[2], (float)X[3]};
+  float scale = xf[3] != 0.f ? 1.f / xf[3] : 1.f;  // convertPointsFromHomogeneous
+  X3[3 * i] = xf[0] * scale; X3[3 * i + 1] = xf[1] * scale; X3[3 * i + 2] = xf[2] * scale;
+}
+
+struct RecoverArgs {
+  double R1[9], R2[9], t[3];
+  CamK cam;
+  const float* p1;
+  const float* p2;
+  const u8* mask_in;  // may be null
+  int n;
+  u8* masks;   // [4][n]
+  int* good;   // [4]
+};
+
+__global__ __launch_bounds__(256) void recover_pose_kernel(RecoverArgs A) {
+  __shared__ int s_good[4];
+  if (threadIdx.x < 4) s_good[threadIdx.x] = 0;
+  __syncthreads();
+  const double dist = 50.0;
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < A.n) {
+    double x1 = (A.p1[2 * i] - A.cam.cx) / A.cam.fx, y1 = (A.p1[2 * i + 1] - A.cam.cy) / A.cam.fy;
+    double x2 = (A.p2[2 * i] - A.cam.cx) / A.cam.fx, y2 = (A.p2[2 * i + 1] - A.cam.cy) / A.cam.fy;
+    const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    for (int c = 0; c < 4; c++) {
+      const double* R = (c & 1) ? A.R2 : A.R1;
+      double sg = c < 2 ? 1.0 : -1.0;
+      double P[12];
+      for (int r = 0; r < 3; r++) {
+        for (int k = 0; k < 3; k++) P[r * 4 + k] = R[r * 3 + k];
+        P[r * 4 + 3] = A.t[r] * sg;
+      }
+      double Q[4];
+      gm_triangulate_one(P0, P, x1, y1, x2, y2, Q);
+      bool m = (Q[2] * Q[3]) > 0;
+      double q0 = Q[0] / Q[3], q1 = Q[1] / Q[3], q2 = Q[2] / Q[3];
+      m = m && (q2 < dist);
+      double z2 = P[8] * q0 + P[9] * q1 + P[10] * q2 + P[11] * 1.0;
+      m = m && (z2 > 0) && (z2 < dist);
+      if (A.mask_in) m = m && (A.mask_in[i] != 0);
+      A.masks[(size_t)c * A.n + i] = m ? 1 : 0;
+      if (m) atomicAdd(&s_good[c], 1);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 4 && s_good[threadIdx.x]) atomicAdd(&A.good[threadIdx.x], s_good[threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+int geom_state_create(mvo_ctx* ctx) {
+  GeomState* g = new GeomState();
+  ctx->geom = g;
+  size_t np = (size_t)ctx->B * ctx->maxpts;
+  MVO_HIP(hipMalloc(&g->d_m1, np * 3 * sizeof(float)));
+  MVO_HIP(hipMalloc(&g->d_m2, np * 2 * sizeof(float)));
+  MVO_HIP(hipMalloc(&g->d_n, ctx->B * sizeof(int)));
+  MVO_HIP(hipMalloc(&g->d_mask, np * 4));
+  MVO_HIP(hipMalloc(&g->d_mask2, np));
+  MVO_HIP(hipMalloc(&g->d_model, (size_t)ctx->B * 16 * sizeof(double)));
+  MVO_HIP(hipMalloc(&g->d_model2, (size_t)ctx->B * 16 * sizeof(double)));
+  MVO_HIP(hipMalloc(&g->d_result, (size_t)ctx->B * 8 * sizeof(int)));
+  MVO_HIP(hipMalloc(&g->d_result2, (size_t)ctx->B * 8 * sizeof(int)));
+  MVO_HIP(hipMalloc(&g->d_inl, np * sizeof(int)));
+  MVO_HIP(hipMalloc(&g->d_pose, (size_t)ctx->B * 8 * sizeof(double)));
+  MVO_HIP(hipMalloc(&g->d_x3, np * 3 * sizeof(float)));
+  MVO_HIP(hipMalloc(&g->d_tmp, 64 * sizeof(double)));
+  MVO_HIP(hipHostMalloc(&g->h_model, (size_t)ctx->B * 16 * sizeof(double) * 3, hipHostMallocDefault));
+  MVO_HIP(hipHostMalloc(&g->h_result, (size_t)ctx->B * 8 * sizeof(int) * 3, hipHostMallocDefault));
+  MVO_HIP(hipMemsetAsync(g->d_result, 0, (size_t)ctx->B * 8 * sizeof(int), ctx->stream));
+  MVO_HIP(hipMemsetAsync(g->d_result2, 0, (size_t)ctx->B * 8 * sizeof(int), ctx->stream));
+  return MVO_OK;
+}
+
+void geom_state_destroy(mvo_ctx* ctx) {
+  GeomState* g = ctx->geom;
+  if (!g) return;
+  void* dev[] = {g->d_m1, g->d_m2, g->d_n, g->d_mask, g->d_mask2, g->d_model, g->d_model2, g->d_result, g->d_result2, g->d_inl,
+                 g->d_pose, g->d_x3, g->d_tmp};
+  for (void* p : dev) (void)hipFree(p);
+  if (g->h_model) (void)hipHostFree(g->h_model);
+  if (g->h_result) (void)hipHostFree(g->h_result);
+  delete g;
+  ctx->geom = nullptr;
+}
+
+template <class M>
+static void launch_ransac(mvo_ctx* ctx, int nslots, const float* m1, const float* m2, int stride1, int stride2, const int* d_n,
+                          double thr, double conf, int max_iters, const ModelParams& P, u8* mask, int mask_stride, double* model,
+                          int* result) {
+  RansacArgs A;
+  A.m1 = m1; A.m2 = m2; A.stride1 = stride1; A.stride2 = stride2; A.n = d_n;
+  A.thr = thr; A.conf = conf; A.max_iters = max_iters; A.cap = ctx->maxpts; A.P = P;
+  A.mask = mask; A.mask_stride = mask_stride; A.model = model; A.result = result;
+  hipLaunchKernelGGL(ransac_kernel<M>, dim3(nslots), dim3(256), 0, ctx->stream, A);
+}
+
+// Device-level drivers used by the pipeline (inputs already resident, all slots per launch).
+int geom_ransac_h(mvo_ctx* ctx, int nslots, const float* p1, const float* p2, const int* d_n, double thr, int max_iters, double conf,
+                  u8* mask, double* model, int* result) {
+  ModelParams P{};
+  launch_ransac<HModel>(ctx, nslots, p1, p2, ctx->maxpts * 2, ctx->maxpts * 2, d_n, thr, conf, max_iters, P, mask, ctx->maxpts, model, result);
+  return MVO_OK;
+}
+int geom_ransac_f(mvo_ctx* ctx, int nslots, const float* p1, const float* p2, const int* d_n, double thr, int max_iters, double conf,
+                  u8* mask, double* model, int* result) {
+  ModelParams P{};
+  launch_ransac<FModel>(ctx, nslots, p1, p2, ctx->maxpts * 2, ctx->maxpts * 2, d_n, thr, conf, max_iters, P, mask, ctx->maxpts, model, result);
+  return MVO_OK;
+}
+static void dbg_sync(mvo_ctx* ctx, const char* what) {
+  static int on = -1;
+  if (on < 0) on = getenv("MVO_DEBUG_SYNC") ? 1 : 0;
+  if (!on) return;
+  fprintf(stderr, "[mvo] launched %s ...", what); fflush(stderr);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  fprintf(stderr, " done (%s)\n", hipGetErrorString(e)); fflush(stderr);
+}
+
+int geom_pnp(mvo_ctx* ctx, int nslots, const float* obj, const float* img, const int* d_n, const double K[9], int iters, float reproj,
+             double conf, u8* mask, double* model, int* result, int* inl, double* pose) {
+  ModelParams P{};
+  P.cam = CamK{K[0], K[4], K[2], K[5]};
+  launch_ransac<PnPModel>(ctx, nslots, obj, img, ctx->maxpts * 3, ctx->maxpts * 2, d_n, (double)reproj, conf, iters, P, mask, ctx->maxpts,
+                          model, result);
+  dbg_sync(ctx, "ransac_kernel<PnP>");
+  hipLaunchKernelGGL(mask_to_indices_kernel, dim3(nslots), dim3(1024), 0, ctx->stream, mask, ctx->maxpts, d_n, inl, ctx->maxpts, result);
+  PnpRefineArgs R;
+  R.obj = obj; R.img = img; R.stride_pts = ctx->maxpts; R.inl = inl; R.result = result; R.model = model; R.n = d_n; R.pose = pose; R.cam = P.cam;
+  dbg_sync(ctx, "mask_to_indices");
+  hipLaunchKernelGGL(pnp_refine_kernel, dim3(nslots), dim3(PR_T), 0, ctx->stream, R);
+  dbg_sync(ctx, "pnp_refine_kernel");
+  return MVO_OK;
+}
 
 int pipe_geometry_stages(mvo_ctx*, unsigned, mvo_step_result*) { return MVO_OK; }
+
+static int upload_pairs(mvo_ctx* ctx, const float* p1, int c1, const float* p2, int c2, int n) {
+  GeomState* g = ctx->geom;
+  if (n > ctx->maxpts) { ctx->set_error("point count exceeds max_points"); return MVO_E_CAPACITY; }
+  if (n > 0) {
+    MVO_HIP(hipMemcpyAsync(g->d_m1, p1, (size_t)n * c1 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    MVO_HIP(hipMemcpyAsync(g->d_m2, p2, (size_t)n * c2 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  }
+  int* hn = (int*)ctx->h_pin;  // pinned: the async copy must not read a dead stack slot
+  hn[0] = n;
+  MVO_HIP(hipMemcpyAsync(g->d_n, hn, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  return MVO_OK;
+}
+
+extern "C" int mvo_find_homography_ransac(mvo_ctx* ctx, const float* p1, const float* p2, int n, double thr, int max_iters,
+                                          double confidence, uint8_t* mask, double H[9], int* n_inliers) {
+  if (!ctx || !p1 || !p2 || !mask || n < 0) return MVO_E_ARG;
+  if (n < 4) { ctx->set_error("findHomography needs at least 4 correspondences"); return MVO_E_ARG; }
+  if (thr <= 0) thr = 3;
+  GeomState* g = ctx->geom;
+  int rc = upload_pairs(ctx, p1, 2, p2, 2, n);
+  if (rc) return rc;
+  geom_ransac_h(ctx, 1, g->d_m1, g->d_m2, g->d_n, thr, max_iters, confidence, g->d_mask, g->d_model, g->d_result);
+  MVO_HIP(hipMemcpyAsync(mask, g->d_mask, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  MVO_HIP(hipMemcpyAsync(g->h_model, g->d_model, 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MVO_HIP(hipMemcpyAsync(g->h_result, g->d_result, 8 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  MVO_HIP(hipStreamSynchronize(ctx->stream));
+  if (n_inliers) *n_inliers = g->h_result[0] ? g->h_result[1] : 0;
+  if (!g->h_result[0]) return MVO_E_DEGENERATE;
+  if (H) memcpy(H, g->h_model, 9 * sizeof(double));
+  return MVO_OK;
+}
+
+extern "C" int mvo_find_fundamental_ransac(mvo_ctx* ctx, const float* p1, const float* p2, int n, double thr, double confidence,
+                                           int max_iters, uint8_t* mask, double F[9], int* n_inliers) {
+  if (!ctx || !p1 || !p2 || !mask || n < 0) return MVO_E_ARG;
+  if (n_inliers) *n_inliers = 0;
+  if (n < 7) return MVO_E_DEGENERATE;  // OpenCV returns an empty Mat, mask untouched
+  if (n > 7 && n < 15) { ctx->set_error("findFundamentalMat LMedS branch (8 <= n < 15) is not built"); return MVO_E_ARG; }
+  if (thr <= 0) thr = 3;
+  if (confidence < DBL_EPSILON || confidence > 1 - DBL_EPSILON) confidence = 0.99;
+  GeomState* g = ctx->geom;
+  int rc = upload_pairs(ctx, p1, 2, p2, 2, n);
+  if (rc) return rc;
+  geom_ransac_f(ctx, 1, g->d_m1, g->d_m2, g->d_n, thr, max_iters, confidence, g->d_mask, g->d_model, g->d_result);
+  MVO_HIP(hipMemcpyAsync(mask, g->d_mask, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  MVO_HIP(hipMemcpyAsync(g->h_model, g->d_model, 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MVO_HIP(hipMemcpyAsync(g->h_result, g->d_result, 8 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  MVO_HIP(hipStreamSynchronize(ctx->stream));
+  if (n_inliers) *n_inliers = g->h_result[0] ? g->h_result[1] : 0;
+  if (!g->h_result[0]) return MVO_E_DEGENERATE;
+  if (F) memcpy(F, g->h_model, 9 * sizeof(double));
+  return MVO_OK;
+}
+
+extern "C" int mvo_solve_pnp_ransac(mvo_ctx* ctx, const float* obj, const float* img, int n, const double K[9], const double d[5],
+                                    int iters, float reproj_err, double confidence, double rvec[3], double tvec[3], int* inlier_idx,
+                                    int* n_inliers) {
+  if (!ctx || !obj || !img || !K || !rvec || !tvec || n < 0) return MVO_E_ARG;
+  if (n_inliers) *n_inliers = 0;
+  if (d)
+    for (int i = 0; i < 5; i++)
+      if (d[i] != 0.0) { ctx->set_error("non-zero distortion is not built (rectified input expected)"); return MVO_E_ARG; }
+  if (n < 5) { ctx->set_error("solvePnPRansac: fewer than 5 points (P3P branch not built)"); return MVO_E_ARG; }
+  GeomState* g = ctx->geom;
+  int rc = upload_pairs(ctx, obj, 3, img, 2, n);
+  if (rc) return rc;
+  geom_pnp(ctx, 1, g->d_m1, g->d_m2, g->d_n, K, iters, reproj_err, confidence, g->d_mask, g->d_model, g->d_result, g->d_inl, g->d_pose);
+  MVO_HIP(hipMemcpyAsync(g->h_model, g->d_pose, 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MVO_HIP(hipMemcpyAsync(g->h_result, g->d_result, 8 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  MVO_HIP(hipStreamSynchronize(ctx->stream));
+  if (!g->h_result[0] || !g->h_result[6]) return MVO_E_DEGENERATE;
+  int cnt = g->h_result[5];
+  for (int i = 0; i < 3; i++) { rvec[i] = g->h_model[i]; tvec[i] = g->h_model[3 + i]; }
+  if (n_inliers) *n_inliers = cnt;
+  if (inlier_idx && cnt > 0) {
+    MVO_HIP(hipMemcpyAsync(inlier_idx, g->d_inl, (size_t)cnt * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MVO_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return MVO_OK;
+}
+
+extern "C" int mvo_triangulate(mvo_ctx* ctx, const double P1[12], const double P2[12], const float* p1, const float* p2, int n,
+                               float* X3) {
+  if (!ctx || !P1 || !P2 || n < 0 || (n && (!p1 || !p2 || !X3))) return MVO_E_ARG;
+  if (n == 0) return MVO_OK;
+  GeomState* g = ctx->geom;
+  int rc = upload_pairs(ctx, p1, 2, p2, 2, n);
+  if (rc) return rc;
+  Proj2 P;
+  memcpy(P.P1, P1, sizeof(P.P1));
+  memcpy(P.P2, P2, sizeof(P.P2));
+  hipLaunchKernelGGL(triangulate_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, P, g->d_m1, g->d_m2, n, g->d_x3);
+  MVO_HIP(hipMemcpyAsync(X3, g->d_x3, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  MVO_HIP(hipStreamSynchronize(ctx->stream));
+  return MVO_OK;
+}
+
+__global__ void decompose_essential_kernel(const double* __restrict__ E, double* __restrict__ out /* R1[9] R2[9] t[3] */) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double e[9], w[3], U[9], Vt[9];
+  for (int i = 0; i < 9; i++) e[i] = E[i];
+  gl_svd3(e, w, U, Vt);
+  if (gl_det3(U) < 0) for (int i = 0; i < 9; i++) U[i] *= -1.;
+  if (gl_det3(Vt) < 0) for (int i = 0; i < 9; i++) Vt[i] *= -1.;
+  const double Wm[9] = {0, 1, 0, -1, 0, 0, 0, 0, 1};
+  const double Wt[9] = {0, -1, 0, 1, 0, 0, 0, 0, 1};
+  double tmp[9];
+  gl_mat3mul(U, Wm, tmp); gl_mat3mul(tmp, Vt, out);
+  gl_mat3mul(U, Wt, tmp); gl_mat3mul(tmp, Vt, out + 9);
+  out[18] = U[2]; out[19] = U[5]; out[20] = U[8];
+}
+
+extern "C" int mvo_recover_pose(mvo_ctx* ctx, const double E[9], const float* p1, const float* p2, int n, const double K[9],
+                                double R[9], double t[3], uint8_t* mask_io, int* n_good) {
+  if (!ctx || !E || !p1 || !p2 || !K || !R || !t || n < 1) return MVO_E_ARG;
+  GeomState* g = ctx->geom;
+  int rc = upload_pairs(ctx, p1, 2, p2, 2, n);
+  if (rc) return rc;
+  double* dE = g->d_tmp;
+  double* dOut = g->d_tmp + 16;
+  MVO_HIP(hipMemcpyAsync(dE, E, 9 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(decompose_essential_kernel, dim3(1), dim3(64), 0, ctx->stream, dE, dOut);
+  MVO_HIP(hipMemcpyAsync(g->h_model, dOut, 21 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MVO_HIP(hipStreamSynchronize(ctx->stream));
+  RecoverArgs A;
+  memcpy(A.R1, g->h_model, 9 * sizeof(double));
+  memcpy(A.R2, g->h_model + 9, 9 * sizeof(double));
+  memcpy(A.t, g->h_model + 18, 3 * sizeof(double));
+  A.cam = CamK{K[0], K[4], K[2], K[5]};
+  A.p1 = g->d_m1; A.p2 = g->d_m2; A.n = n;
+  A.mask_in = nullptr;
+  if (mask_io) {
+    MVO_HIP(hipMemcpyAsync(g->d_mask2, mask_io, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    A.mask_in = g->d_mask2;
+  }
+  A.masks = g->d_mask;  // 4 * maxpts bytes
+  A.good = g->d_result2;
+  MVO_HIP(hipMemsetAsync(g->d_result2, 0, 4 * sizeof(int), ctx->stream));
+  hipLaunchKernelGGL(recover_pose_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, A);
+  MVO_HIP(hipMemcpyAsync(g->h_result, g->d_result2, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  MVO_HIP(hipStreamSynchronize(ctx->stream));
+  const int* good = g->h_result;
+  int best;
+  if (good[0] >= good[1] && good[0] >= good[2] && good[0] >= good[3]) best = 0;
+  else if (good[1] >= good[0] && good[1] >= good[2] && good[1] >= good[3]) best = 1;
+  else if (good[2] >= good[0] && good[2] >= good[1] && good[2] >= good[3]) best = 2;
+  else best = 3;
+  memcpy(R, (best & 1) ? A.R2 : A.R1, 9 * sizeof(double));
+  for (int k = 0; k < 3; k++) t[k] = best < 2 ? A.t[k] : -A.t[k];
+  if (mask_io) {
+    MVO_HIP(hipMemcpyAsync(mask_io, g->d_mask + (size_t)best * n, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    MVO_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  if (n_good) *n_good = good[best];
+  return MVO_OK;
+}
+
+extern "C" int mvo_find_essential_ransac(mvo_ctx* ctx, const float*, const float*, int, const double*, double, double, int, uint8_t*,
+                                         double*, int*) {
+  if (ctx) ctx->set_error("mvo_find_essential_ransac: 5-point solver not built yet");
+  return MVO_E_ARG;
+}

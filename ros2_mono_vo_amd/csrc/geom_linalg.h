@@ -1,0 +1,436 @@
+// csrc/geom_linalg.h — per-lane dense linear algebra for the RANSAC solvers (device code).
+//
+// Every lane of a wavefront solves its own minimal problem, so these are plain sequential routines on
+// small row-major double matrices held in per-lane (private) arrays.  They follow the OpenCV numerics the
+// reference's calib3d calls run on (core/src/lapack.cpp JacobiImpl_ / JacobiSVDImpl_ / SVBkSbImpl_ / LUImpl,
+// mathfuncs.cpp solveCubic) operation by operation, with -ffp-contract=off, so that a lane reproduces the
+// CPU sequence bit for bit wherever no libm call is involved (hypot is the explicit scaled form).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <float.h>
+
+#define GL_MAXN 12
+
+// The dense kernels below are deliberately NOT inlined: a minimal solver calls the Jacobi SVD a dozen
+// times, and inlining every copy produced single functions > 128 KB whose long-branch expansion
+// (s_setpc through a scratch SGPR pair) corrupted control flow on gfx950 / ROCm 7.2.
+#define GL_NOINLINE __attribute__((noinline))
+
+
+__device__ __forceinline__ void gl_swap(double& a, double& b) { double t = a; a = b; b = t; }
+
+__device__ __forceinline__ double gl_hypot(double a, double b) {
+  a = fabs(a); b = fabs(b);
+  if (a < b) gl_swap(a, b);
+  if (a == 0.0) return 0.0;
+  double t = b / a;
+  return a * sqrt(1.0 + t * t);
+}
+
+// cv::RNG (64-bit multiply-with-carry)
+struct GlRng {
+  unsigned long long state;
+  __device__ explicit GlRng(unsigned long long s) : state(s ? s : 0xffffffffULL) {}
+  __device__ __forceinline__ unsigned next() {
+    state = (unsigned long long)(unsigned)state * 4164903690U + (unsigned)(state >> 32);
+    return (unsigned)state;
+  }
+  __device__ __forceinline__ int uniform(int a, int b) { return a == b ? a : (int)(next() % (unsigned)(b - a) + a); }
+};
+
+// cv::eigen (symmetric) — JacobiImpl_.  A n x n destroyed; W descending; V eigenvectors in rows.
+__device__ GL_NOINLINE void gl_jacobi_eigen(double* A, int n, double* W, double* V) {
+  const double eps = DBL_EPSILON;
+  int i, j, k, m;
+  int indR[GL_MAXN], indC[GL_MAXN];
+  for (i = 0; i < n; i++) {
+    for (j = 0; j < n; j++) V[i * n + j] = 0;
+    V[i * n + i] = 1;
+  }
+  int iters, maxIters = n * n * 30;
+  double mv = 0;
+  for (k = 0; k < n; k++) {
+    W[k] = A[(n + 1) * k];
+    if (k < n - 1) {
+      for (m = k + 1, mv = fabs(A[n * k + m]), i = k + 2; i < n; i++) {
+        double val = fabs(A[n * k + i]);
+        if (mv < val) mv = val, m = i;
+      }
+      indR[k] = m;
+    }
+    if (k > 0) {
+      for (m = 0, mv = fabs(A[k]), i = 1; i < k; i++) {
+        double val = fabs(A[n * i + k]);
+        if (mv < val) mv = val, m = i;
+      }
+      indC[k] = m;
+    }
+  }
+  if (n > 1)
+    for (iters = 0; iters < maxIters; iters++) {
+      for (k = 0, mv = fabs(A[indR[0]]), i = 1; i < n - 1; i++) {
+        double val = fabs(A[n * i + indR[i]]);
+        if (mv < val) mv = val, k = i;
+      }
+      int l = indR[k];
+      for (i = 1; i < n; i++) {
+        double val = fabs(A[n * indC[i] + i]);
+        if (mv < val) mv = val, k = indC[i], l = i;
+      }
+      double p = A[n * k + l];
+      if (fabs(p) <= eps) break;
+      double y = (W[l] - W[k]) * 0.5;
+      double t = fabs(y) + gl_hypot(p, y);
+      double s = gl_hypot(p, t);
+      double c = t / s;
+      s = p / s;
+      t = (p / t) * p;
+      if (y < 0) s = -s, t = -t;
+      A[n * k + l] = 0;
+      W[k] -= t;
+      W[l] += t;
+      double a0, b0;
+#define GL_ROT(v0, v1) a0 = v0, b0 = v1, v0 = a0 * c - b0 * s, v1 = a0 * s + b0 * c
+      for (i = 0; i < k; i++) GL_ROT(A[n * i + k], A[n * i + l]);
+      for (i = k + 1; i < l; i++) GL_ROT(A[n * k + i], A[n * i + l]);
+      for (i = l + 1; i < n; i++) GL_ROT(A[n * k + i], A[n * l + i]);
+      for (i = 0; i < n; i++) GL_ROT(V[n * k + i], V[n * l + i]);
+#undef GL_ROT
+      for (j = 0; j < 2; j++) {
+        int idx = j == 0 ? k : l;
+        if (idx < n - 1) {
+          for (m = idx + 1, mv = fabs(A[n * idx + m]), i = idx + 2; i < n; i++) {
+            double val = fabs(A[n * idx + i]);
+            if (mv < val) mv = val, m = i;
+          }
+          indR[idx] = m;
+        }
+        if (idx > 0) {
+          for (m = 0, mv = fabs(A[idx]), i = 1; i < idx; i++) {
+            double val = fabs(A[n * i + idx]);
+            if (mv < val) mv = val, m = i;
+          }
+          indC[idx] = m;
+        }
+      }
+    }
+  for (k = 0; k < n - 1; k++) {
+    m = k;
+    for (i = k + 1; i < n; i++)
+      if (W[m] < W[i]) m = i;
+    if (k != m) {
+      gl_swap(W[m], W[k]);
+      for (i = 0; i < n; i++) gl_swap(V[n * m + i], V[n * k + i]);
+    }
+  }
+}
+
+// JacobiSVDImpl_<double>: At has n rows of length m (stride astep); rows 0..n1-1 become left singular
+// vectors (the rows beyond n are the seeded Gram-Schmidt completion); Vt n x n.
+__device__ GL_NOINLINE void gl_jacobi_svd(double* At, int astep, double* Wout, double* Vt, int m, int n, int n1) {
+  const double minval = DBL_MIN, eps = DBL_EPSILON * 10;
+  double W[GL_MAXN];
+  int i, j, k, iter, max_iter = m > 30 ? m : 30;
+  double c, s, sd;
+  for (i = 0; i < n; i++) {
+    for (k = 0, sd = 0; k < m; k++) {
+      double t = At[i * astep + k];
+      sd += t * t;
+    }
+    W[i] = sd;
+    if (Vt) {
+      for (k = 0; k < n; k++) Vt[i * n + k] = 0;
+      Vt[i * n + i] = 1;
+    }
+  }
+  for (iter = 0; iter < max_iter; iter++) {
+    bool changed = false;
+    for (i = 0; i < n - 1; i++)
+      for (j = i + 1; j < n; j++) {
+        double *Ai = At + i * astep, *Aj = At + j * astep;
+        double a = W[i], p = 0, b = W[j];
+        for (k = 0; k < m; k++) p += Ai[k] * Aj[k];
+        if (fabs(p) <= eps * sqrt(a * b)) continue;
+        p *= 2;
+        double beta = a - b, gamma = gl_hypot(p, beta);
+        if (beta < 0) {
+          double delta = (gamma - beta) * 0.5;
+          s = sqrt(delta / gamma);
+          c = p / (gamma * s * 2);
+        } else {
+          c = sqrt((gamma + beta) / (gamma * 2));
+          s = p / (gamma * c * 2);
+        }
+        a = b = 0;
+        for (k = 0; k < m; k++) {
+          double t0 = c * Ai[k] + s * Aj[k];
+          double t1 = -s * Ai[k] + c * Aj[k];
+          Ai[k] = t0; Aj[k] = t1;
+          a += t0 * t0; b += t1 * t1;
+        }
+        W[i] = a; W[j] = b;
+        changed = true;
+        if (Vt) {
+          double *Vi = Vt + i * n, *Vj = Vt + j * n;
+          for (k = 0; k < n; k++) {
+            double t0 = c * Vi[k] + s * Vj[k];
+            double t1 = -s * Vi[k] + c * Vj[k];
+            Vi[k] = t0; Vj[k] = t1;
+          }
+        }
+      }
+    if (!changed) break;
+  }
+  for (i = 0; i < n; i++) {
+    for (k = 0, sd = 0; k < m; k++) {
+      double t = At[i * astep + k];
+      sd += t * t;
+    }
+    W[i] = sqrt(sd);
+  }
+  for (i = 0; i < n - 1; i++) {
+    j = i;
+    for (k = i + 1; k < n; k++)
+      if (W[j] < W[k]) j = k;
+    if (i != j) {
+      gl_swap(W[i], W[j]);
+      if (Vt) {
+        for (k = 0; k < m; k++) gl_swap(At[i * astep + k], At[j * astep + k]);
+        for (k = 0; k < n; k++) gl_swap(Vt[i * n + k], Vt[j * n + k]);
+      }
+    }
+  }
+  for (i = 0; i < n; i++) Wout[i] = W[i];
+  if (!Vt) return;
+  GlRng rng(0x12345678);
+  for (i = 0; i < n1; i++) {
+    sd = i < n ? W[i] : 0;
+    for (int ii = 0; ii < 100 && sd <= minval; ii++) {
+      const double val0 = 1. / m;
+      for (k = 0; k < m; k++) {
+        double val = (rng.next() & 256) != 0 ? val0 : -val0;
+        At[i * astep + k] = val;
+      }
+      for (iter = 0; iter < 2; iter++) {
+        for (j = 0; j < i; j++) {
+          sd = 0;
+          for (k = 0; k < m; k++) sd += At[i * astep + k] * At[j * astep + k];
+          double asum = 0;
+          for (k = 0; k < m; k++) {
+            double t = At[i * astep + k] - sd * At[j * astep + k];
+            At[i * astep + k] = t;
+            asum += fabs(t);
+          }
+          asum = asum > eps * 100 ? 1 / asum : 0;
+          for (k = 0; k < m; k++) At[i * astep + k] *= asum;
+        }
+      }
+      sd = 0;
+      for (k = 0; k < m; k++) {
+        double t = At[i * astep + k];
+        sd += t * t;
+      }
+      sd = sqrt(sd);
+    }
+    s = sd > minval ? 1 / sd : 0.;
+    for (k = 0; k < m; k++) At[i * astep + k] *= s;
+  }
+}
+
+// cv::SVD::compute(A (m x n)).  Scratch buffers ta (max(m,n)^2 when full_uv, else min*max) and tv (min^2)
+// are supplied by the caller.  U (m x ucols) and Vt (vrows x n) may be null.
+__device__ GL_NOINLINE void gl_svd_compute(const double* A, int m, int n, double* w, double* U, double* Vt, bool full_uv,
+                                      double* ta, double* tv) {
+  bool at = false;
+  int mm = m, nn = n;
+  if (mm < nn) { int t = mm; mm = nn; nn = t; at = true; }
+  int urows = full_uv ? mm : nn;
+  for (int i = 0; i < urows * mm; i++) ta[i] = 0.0;
+  if (!at) {
+    for (int i = 0; i < m; i++)
+      for (int j = 0; j < n; j++) ta[j * mm + i] = A[i * n + j];
+  } else {
+    for (int i = 0; i < m; i++)
+      for (int j = 0; j < n; j++) ta[i * mm + j] = A[i * n + j];
+  }
+  gl_jacobi_svd(ta, mm, w, tv, mm, nn, urows);
+  if (!at) {
+    if (U)
+      for (int i = 0; i < urows; i++)
+        for (int k = 0; k < mm; k++) U[k * urows + i] = ta[i * mm + k];
+    if (Vt)
+      for (int i = 0; i < nn * nn; i++) Vt[i] = tv[i];
+  } else {
+    if (U)
+      for (int i = 0; i < nn; i++)
+        for (int k = 0; k < nn; k++) U[k * nn + i] = tv[i * nn + k];
+    if (Vt)
+      for (int i = 0; i < urows * mm; i++) Vt[i] = ta[i];
+  }
+}
+
+// SVBkSbImpl_ (uT = vT = true).  b == nullptr -> pseudo-inverse (nb = m).  buffer: nb doubles.
+__device__ GL_NOINLINE void gl_svbksb(int m, int n, const double* w, const double* Ut, int ldu, const double* Vt, int ldv,
+                                 const double* b, int ldb, int nb, double* x, int ldx, double* buffer) {
+  const double eps = DBL_EPSILON * 2;
+  double threshold = 0;
+  int nm = m < n ? m : n;
+  if (!b) nb = m;
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < nb; j++) x[i * ldx + j] = 0;
+  for (int i = 0; i < nm; i++) threshold += w[i];
+  threshold *= eps;
+  for (int i = 0; i < nm; i++) {
+    const double* u = Ut + i * ldu;
+    const double* v = Vt + i * ldv;
+    double wi = w[i];
+    if (fabs(wi) <= threshold) continue;
+    wi = 1 / wi;
+    if (nb == 1) {
+      double s = 0;
+      if (b)
+        for (int j = 0; j < m; j++) s += u[j] * b[j * ldb];
+      else
+        s = u[0];
+      s *= wi;
+      for (int j = 0; j < n; j++) x[j * ldx] = x[j * ldx] + s * v[j];
+    } else {
+      if (b) {
+        for (int j = 0; j < nb; j++) buffer[j] = 0;
+        for (int k = 0; k < m; k++) {
+          double s = u[k];
+          for (int j = 0; j < nb; j++) buffer[j] = buffer[j] + s * b[k * ldb + j];
+        }
+        for (int j = 0; j < nb; j++) buffer[j] *= wi;
+      } else {
+        for (int j = 0; j < nb; j++) buffer[j] = u[j] * wi;
+      }
+      for (int k = 0; k < n; k++) {
+        double s = v[k];
+        for (int j = 0; j < nb; j++) x[k * ldx + j] = x[k * ldx + j] + s * buffer[j];
+      }
+    }
+  }
+}
+
+// cv::solve(A (m x n, m >= n <= 6), b, x, DECOMP_SVD)
+__device__ inline void gl_solve_svd(const double* A, int m, int n, const double* b, double* x) {
+  double at[36], w[6], vt[36], buf[1];
+  for (int i = 0; i < m; i++)
+    for (int j = 0; j < n; j++) at[j * m + i] = A[i * n + j];
+  gl_jacobi_svd(at, m, w, vt, m, n, n);
+  gl_svbksb(m, n, w, at, m, vt, n, b, 1, 1, x, 1, buf);
+}
+
+// cv::invert(A 3x3, DECOMP_SVD)
+__device__ inline void gl_invert3_svd(const double* A, double* Ainv) {
+  double at[9], w[3], vt[9], buf[3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) at[j * 3 + i] = A[i * 3 + j];
+  gl_jacobi_svd(at, 3, w, vt, 3, 3, 3);
+  gl_svbksb(3, 3, w, at, 3, vt, 3, nullptr, 0, 3, Ainv, 3, buf);
+}
+
+// SVD of a 3x3 (U, w, Vt)
+__device__ inline void gl_svd3(const double* A, double* w, double* U, double* Vt) {
+  double ta[9], tv[9];
+  gl_svd_compute(A, 3, 3, w, U, Vt, false, ta, tv);
+}
+
+// cv::solveCubic (4 double coefficients)
+__device__ GL_NOINLINE int gl_solve_cubic(const double c[4], double x[3]) {
+  double a0 = c[0], a1 = c[1], a2 = c[2], a3 = c[3];
+  double x0 = 0., x1 = 0., x2 = 0.;
+  int n = 0;
+  if (a0 == 0) {
+    if (a1 == 0) {
+      if (a2 == 0) n = a3 == 0 ? -1 : 0;
+      else { x0 = -a3 / a2; n = 1; }
+    } else {
+      double d = a2 * a2 - 4 * a1 * a3;
+      if (d >= 0) {
+        d = sqrt(d);
+        double q1 = (-a2 + d) * 0.5;
+        double q2 = (a2 + d) * -0.5;
+        if (fabs(q1) > fabs(q2)) { x0 = q1 / a1; x1 = a3 / q1; }
+        else { x0 = q2 / a1; x1 = a3 / q2; }
+        n = d > 0 ? 2 : 1;
+      }
+    }
+  } else {
+    a0 = 1. / a0;
+    a1 *= a0; a2 *= a0; a3 *= a0;
+    double Q = (a1 * a1 - 3 * a2) * (1. / 9);
+    double R = (2 * a1 * a1 * a1 - 9 * a1 * a2 + 27 * a3) * (1. / 54);
+    double Qcubed = Q * Q * Q;
+    double d = Qcubed - R * R;
+    if (d > 0) {
+      double theta = acos(R / sqrt(Qcubed));
+      double sqrtQ = sqrt(Q);
+      double t0 = -2 * sqrtQ;
+      double t1 = theta * (1. / 3);
+      double t2 = a1 * (1. / 3);
+      x0 = t0 * cos(t1) - t2;
+      x1 = t0 * cos(t1 + (2. * M_PI / 3)) - t2;
+      x2 = t0 * cos(t1 + (4. * M_PI / 3)) - t2;
+      n = 3;
+    } else if (d == 0) {
+      if (R >= 0) {
+        x0 = -2 * pow(R, 1. / 3) - a1 / 3;
+        x1 = pow(R, 1. / 3) - a1 / 3;
+      } else {
+        x0 = 2 * pow(-R, 1. / 3) - a1 / 3;
+        x1 = -pow(-R, 1. / 3) - a1 / 3;
+      }
+      x2 = 0;
+      n = x0 == x1 ? 1 : 2;
+      x1 = x0 == x1 ? 0 : x1;
+    } else {
+      double e;
+      d = sqrt(-d);
+      e = pow(d + fabs(R), 1. / 3);
+      if (R > 0) e = -e;
+      x0 = (e + Q / e) - a1 * (1. / 3);
+      n = 1;
+    }
+  }
+  x[0] = x0; x[1] = x1; x[2] = x2;
+  return n;
+}
+
+__device__ __forceinline__ double gl_det3(const double* M) {
+  return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+__device__ inline void gl_mat3mul(const double* A, const double* B, double* C) {
+  double t[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) t[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+  for (int i = 0; i < 9; i++) C[i] = t[i];
+}
+
+// RANSACUpdateNumIters (ptsetreg.cpp)
+__device__ GL_NOINLINE int gl_ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters) {
+  p = fmax(p, 0.); p = fmin(p, 1.);
+  ep = fmax(ep, 0.); ep = fmin(ep, 1.);
+  double num = fmax(1. - p, DBL_MIN);
+  double denom = 1. - pow(1. - ep, (double)modelPoints);
+  if (denom < DBL_MIN) return 0;
+  num = log(num);
+  denom = log(denom);
+  return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : __double2int_rn(num / denom);
+}
+
+// haveCollinearPoints<float>: only the last point against earlier pairs
+__device__ GL_NOINLINE bool gl_have_collinear(const float* pts, int count) {
+  int i = count - 1;
+  for (int j = 0; j < i; j++) {
+    double dx1 = pts[2 * j] - pts[2 * i];
+    double dy1 = pts[2 * j + 1] - pts[2 * i + 1];
+    for (int k = 0; k < j; k++) {
+      double dx2 = pts[2 * k] - pts[2 * i];
+      double dy2 = pts[2 * k + 1] - pts[2 * i + 1];
+      if (fabs(dx2 * dy1 - dy2 * dx1) <= FLT_EPSILON * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2))) return true;
+    }
+  }
+  return false;
+}

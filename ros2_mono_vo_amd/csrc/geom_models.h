@@ -1,0 +1,630 @@
+// csrc/geom_models.h — minimal solvers + residuals of the RANSAC models (device code, one hypothesis per
+// lane).  Each model policy provides:
+//   MP          sample size            MAXM   models per sample        MS   doubles per model
+//   PT1 / PT2   floats per point in set 1 / set 2
+//   check_subset(ms1, ms2)             OpenCV's Callback::checkSubset
+//   solve(P, ms1, ms2, models)         OpenCV's Callback::runKernel   -> number of models
+//   Scorer                             per-model constants + err(p1, p2) -> float (Callback::computeError)
+// Semantics: OpenCV 4.6 calib3d (fundam.cpp, solvepnp.cpp, epnp.cpp, calibration.cpp) as restated in
+// SURVEY.md Appendix A.5-A.7; arithmetic order matches oracle/orc_geom.cpp / orc_pnp.cpp.
+#pragma once
+#include "geom_linalg.h"
+
+struct CamK { double fx, fy, cx, cy; };
+struct ModelParams { CamK cam; };
+
+// ---------------------------------------------------------------------------------------------------
+// Homography, 4 points (HomographyEstimatorCallback)
+// ---------------------------------------------------------------------------------------------------
+struct HModel {
+  static constexpr int MP = 4, MAXM = 1, MS = 9, PT1 = 2, PT2 = 2;
+
+  __device__ static bool check_subset(const float* ms1, const float* ms2) {
+    if (gl_have_collinear(ms1, 4) || gl_have_collinear(ms2, 4)) return false;
+    const int tt[4][3] = {{0, 1, 2}, {1, 2, 3}, {0, 2, 3}, {0, 1, 3}};
+    int negative = 0;
+    for (int i = 0; i < 4; i++) {
+      const int* t = tt[i];
+      double A[9] = {ms1[2 * t[0]], ms1[2 * t[0] + 1], 1., ms1[2 * t[1]], ms1[2 * t[1] + 1], 1., ms1[2 * t[2]], ms1[2 * t[2] + 1], 1.};
+      double B[9] = {ms2[2 * t[0]], ms2[2 * t[0] + 1], 1., ms2[2 * t[1]], ms2[2 * t[1] + 1], 1., ms2[2 * t[2]], ms2[2 * t[2] + 1], 1.};
+      negative += gl_det3(A) * gl_det3(B) < 0;
+    }
+    return !(negative != 0 && negative != 4);
+  }
+
+  // runKernel for `count` float points (count = 4 inside RANSAC)
+  __device__ GL_NOINLINE static int solve_n(const float* M, const float* m, int count, double* model) {
+    double LtL[81], W[9], V[81];
+    double cMx = 0, cMy = 0, cmx = 0, cmy = 0, sMx = 0, sMy = 0, smx = 0, smy = 0;
+    for (int i = 0; i < count; i++) {
+      cmx += m[2 * i]; cmy += m[2 * i + 1];
+      cMx += M[2 * i]; cMy += M[2 * i + 1];
+    }
+    cmx /= count; cmy /= count; cMx /= count; cMy /= count;
+    for (int i = 0; i < count; i++) {
+      smx += fabs(m[2 * i] - cmx);
+      smy += fabs(m[2 * i + 1] - cmy);
+      sMx += fabs(M[2 * i] - cMx);
+      sMy += fabs(M[2 * i + 1] - cMy);
+    }
+    if (fabs(smx) < DBL_EPSILON || fabs(smy) < DBL_EPSILON || fabs(sMx) < DBL_EPSILON || fabs(sMy) < DBL_EPSILON) return 0;
+    smx = count / smx; smy = count / smy;
+    sMx = count / sMx; sMy = count / sMy;
+    double invHnorm[9] = {1. / smx, 0, cmx, 0, 1. / smy, cmy, 0, 0, 1};
+    double Hnorm2[9] = {sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1};
+    for (int i = 0; i < 81; i++) LtL[i] = 0;
+    for (int i = 0; i < count; i++) {
+      double x = (m[2 * i] - cmx) * smx, y = (m[2 * i + 1] - cmy) * smy;
+      double X = (M[2 * i] - cMx) * sMx, Y = (M[2 * i + 1] - cMy) * sMy;
+      double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
+      double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
+      for (int j = 0; j < 9; j++)
+        for (int k = j; k < 9; k++) LtL[j * 9 + k] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
+    }
+    for (int j = 0; j < 9; j++)
+      for (int k = 0; k < j; k++) LtL[j * 9 + k] = LtL[k * 9 + j];
+    gl_jacobi_eigen(LtL, 9, W, V);
+    double Htemp[9], H0[9];
+    gl_mat3mul(invHnorm, V + 72, Htemp);
+    gl_mat3mul(Htemp, Hnorm2, H0);
+    double s = 1. / H0[8];
+    for (int i = 0; i < 9; i++) model[i] = H0[i] * s;
+    return 1;
+  }
+  __device__ static int solve(const ModelParams&, const float* ms1, const float* ms2, double* models) {
+    return solve_n(ms1, ms2, 4, models);
+  }
+
+  struct Scorer {
+    float Hf[8];
+    __device__ void init(const ModelParams&, const double* H) {
+      for (int i = 0; i < 8; i++) Hf[i] = (float)H[i];
+    }
+    __device__ __forceinline__ float err(const float* M, const float* m) const {
+      float ww = 1.f / (Hf[6] * M[0] + Hf[7] * M[1] + 1.f);
+      float dx = (Hf[0] * M[0] + Hf[1] * M[1] + Hf[2]) * ww - m[0];
+      float dy = (Hf[3] * M[0] + Hf[4] * M[1] + Hf[5]) * ww - m[1];
+      return dx * dx + dy * dy;
+    }
+  };
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Fundamental matrix, 7 points (FMEstimatorCallback / run7Point)
+// ---------------------------------------------------------------------------------------------------
+struct FModel {
+  static constexpr int MP = 7, MAXM = 3, MS = 9, PT1 = 2, PT2 = 2;
+
+  __device__ static bool check_subset(const float* ms1, const float* ms2) {
+    return !gl_have_collinear(ms1, 7) && !gl_have_collinear(ms2, 7);
+  }
+
+  __device__ GL_NOINLINE static int solve(const ModelParams&, const float* m1, const float* m2, double* fmatrix) {
+    double a[7 * 9], w[7], v[9 * 9], c[4], r[3] = {0, 0, 0};
+    double ta[81], tv[49];
+    double *f1, *f2;
+    double t0, t1, t2;
+    double m1cx = 0, m1cy = 0, m2cx = 0, m2cy = 0;
+    double t, scale1 = 0, scale2 = 0;
+    const int count = 7;
+    for (int i = 0; i < count; i++) {
+      m1cx += m1[2 * i]; m1cy += m1[2 * i + 1];
+      m2cx += m2[2 * i]; m2cy += m2[2 * i + 1];
+    }
+    t = 1. / count;
+    m1cx *= t; m1cy *= t; m2cx *= t; m2cy *= t;
+    for (int i = 0; i < count; i++) {
+      double ax = m1[2 * i] - m1cx, ay = m1[2 * i + 1] - m1cy;
+      double bx = m2[2 * i] - m2cx, by = m2[2 * i + 1] - m2cy;
+      scale1 += sqrt(ax * ax + ay * ay);
+      scale2 += sqrt(bx * bx + by * by);
+    }
+    scale1 *= t; scale2 *= t;
+    if (scale1 < FLT_EPSILON || scale2 < FLT_EPSILON) return 0;
+    scale1 = sqrt(2.) / scale1;
+    scale2 = sqrt(2.) / scale2;
+    for (int i = 0; i < 7; i++) {
+      double x0 = (m1[2 * i] - m1cx) * scale1;
+      double y0 = (m1[2 * i + 1] - m1cy) * scale1;
+      double x1 = (m2[2 * i] - m2cx) * scale2;
+      double y1 = (m2[2 * i + 1] - m2cy) * scale2;
+      a[i * 9 + 0] = x1 * x0; a[i * 9 + 1] = x1 * y0; a[i * 9 + 2] = x1;
+      a[i * 9 + 3] = y1 * x0; a[i * 9 + 4] = y1 * y0; a[i * 9 + 5] = y1;
+      a[i * 9 + 6] = x0; a[i * 9 + 7] = y0; a[i * 9 + 8] = 1;
+    }
+    gl_svd_compute(a, 7, 9, w, nullptr, v, true, ta, tv);
+    f1 = v + 7 * 9;
+    f2 = v + 8 * 9;
+    for (int i = 0; i < 9; i++) f1[i] -= f2[i];
+    t0 = f2[4] * f2[8] - f2[5] * f2[7];
+    t1 = f2[3] * f2[8] - f2[5] * f2[6];
+    t2 = f2[3] * f2[7] - f2[4] * f2[6];
+    c[3] = f2[0] * t0 - f2[1] * t1 + f2[2] * t2;
+    c[2] = f1[0] * t0 - f1[1] * t1 + f1[2] * t2 - f1[3] * (f2[1] * f2[8] - f2[2] * f2[7]) +
+           f1[4] * (f2[0] * f2[8] - f2[2] * f2[6]) - f1[5] * (f2[0] * f2[7] - f2[1] * f2[6]) +
+           f1[6] * (f2[1] * f2[5] - f2[2] * f2[4]) - f1[7] * (f2[0] * f2[5] - f2[2] * f2[3]) +
+           f1[8] * (f2[0] * f2[4] - f2[1] * f2[3]);
+    t0 = f1[4] * f1[8] - f1[5] * f1[7];
+    t1 = f1[3] * f1[8] - f1[5] * f1[6];
+    t2 = f1[3] * f1[7] - f1[4] * f1[6];
+    c[0] = f1[0] * t0 - f1[1] * t1 + f1[2] * t2;
+    c[1] = f2[0] * t0 - f2[1] * t1 + f2[2] * t2 - f2[3] * (f1[1] * f1[8] - f1[2] * f1[7]) +
+           f2[4] * (f1[0] * f1[8] - f1[2] * f1[6]) - f2[5] * (f1[0] * f1[7] - f1[1] * f1[6]) +
+           f2[6] * (f1[1] * f1[5] - f1[2] * f1[4]) - f2[7] * (f1[0] * f1[5] - f1[2] * f1[3]) +
+           f2[8] * (f1[0] * f1[4] - f1[1] * f1[3]);
+    int n = gl_solve_cubic(c, r);
+    if (n < 1 || n > 3) return n;
+    double T1[9] = {scale1, 0, -scale1 * m1cx, 0, scale1, -scale1 * m1cy, 0, 0, 1};
+    double T2t[9] = {scale2, 0, 0, 0, scale2, 0, -scale2 * m2cx, -scale2 * m2cy, 1};
+    for (int k = 0; k < n; k++, fmatrix += 9) {
+      double lambda = r[k], mu = 1.;
+      double s = f1[8] * r[k] + f2[8];
+      if (fabs(s) > DBL_EPSILON) {
+        mu = 1. / s;
+        lambda *= mu;
+        fmatrix[8] = 1.;
+      } else
+        fmatrix[8] = 0.;
+      for (int i = 0; i < 8; i++) fmatrix[i] = f1[i] * lambda + f2[i] * mu;
+      double tmp[9];
+      gl_mat3mul(T2t, fmatrix, tmp);
+      gl_mat3mul(tmp, T1, fmatrix);
+      if (fabs(fmatrix[8]) > FLT_EPSILON) {
+        double sc = 1. / fmatrix[8];
+        for (int i = 0; i < 9; i++) fmatrix[i] *= sc;
+      }
+    }
+    return n;
+  }
+
+  struct Scorer {
+    double F[9];
+    __device__ void init(const ModelParams&, const double* f) {
+      for (int i = 0; i < 9; i++) F[i] = f[i];
+    }
+    __device__ __forceinline__ float err(const float* m1, const float* m2) const {
+      double a, b, c, d1, d2, s1, s2;
+      a = F[0] * m1[0] + F[1] * m1[1] + F[2];
+      b = F[3] * m1[0] + F[4] * m1[1] + F[5];
+      c = F[6] * m1[0] + F[7] * m1[1] + F[8];
+      s2 = 1. / (a * a + b * b);
+      d2 = m2[0] * a + m2[1] * b + c;
+      a = F[0] * m2[0] + F[3] * m2[1] + F[6];
+      b = F[1] * m2[0] + F[4] * m2[1] + F[7];
+      c = F[2] * m2[0] + F[5] * m2[1] + F[8];
+      s1 = 1. / (a * a + b * b);
+      d1 = m1[0] * a + m1[1] * b + c;
+      return (float)fmax(d1 * d1 * s1, d2 * d2 * s2);
+    }
+  };
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Rodrigues / projection (calibration.cpp cvRodrigues2, cvProjectPoints2 with zero distortion)
+// ---------------------------------------------------------------------------------------------------
+__device__ GL_NOINLINE void gm_rodrigues_v2m(const double r_[3], double R[9], double* J /* 27 or null */) {
+  double rx = r_[0], ry = r_[1], rz = r_[2];
+  double theta = sqrt(rx * rx + ry * ry + rz * rz);
+  if (theta < DBL_EPSILON) {
+    for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1 : 0;
+    if (J) {
+      for (int i = 0; i < 27; i++) J[i] = 0;
+      J[5] = J[15] = J[19] = -1;
+      J[7] = J[11] = J[21] = 1;
+    }
+    return;
+  }
+  double c = cos(theta), s = sin(theta), c1 = 1. - c;
+  double itheta = theta ? 1. / theta : 0.;
+  rx *= itheta; ry *= itheta; rz *= itheta;
+  double rrt[9] = {rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz};
+  double r_x[9] = {0, -rz, ry, rz, 0, -rx, -ry, rx, 0};
+  const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int k = 0; k < 9; k++) R[k] = c * I[k] + c1 * rrt[k] + s * r_x[k];
+  if (J) {
+    const double drrt[27] = {rx + rx, ry, rz, ry, 0, 0, rz, 0, 0, 0, rx, 0, rx, ry + ry, rz, 0, rz, 0,
+                             0, 0, rx, 0, 0, ry, rx, ry, rz + rz};
+    const double d_r_x_[27] = {0, 0, 0, 0, 0, -1, 0, 1, 0, 0, 0, 1, 0, 0, 0, -1, 0, 0, 0, -1, 0, 1, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 3; i++) {
+      double ri = i == 0 ? rx : i == 1 ? ry : rz;
+      double a0 = -s * ri, a1 = (s - 2 * c1 * itheta) * ri, a2 = c1 * itheta;
+      double a3 = (c - s * itheta) * ri, a4 = s * itheta;
+      for (int k = 0; k < 9; k++)
+        J[i * 9 + k] = a0 * I[k] + a1 * rrt[k] + a2 * drrt[i * 9 + k] + a3 * r_x[k] + a4 * d_r_x_[i * 9 + k];
+    }
+  }
+}
+
+__device__ GL_NOINLINE void gm_rodrigues_m2v(const double Rin[9], double r[3]) {
+  for (int i = 0; i < 9; i++)
+    if (!(Rin[i] > -100 && Rin[i] < 100)) { r[0] = r[1] = r[2] = 0; return; }
+  double w[3], U[9], Vt[9], R[9];
+  gl_svd3(Rin, w, U, Vt);
+  gl_mat3mul(U, Vt, R);
+  double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
+  double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+  double c = (R[0] + R[4] + R[8] - 1) * 0.5;
+  c = c > 1. ? 1. : c < -1. ? -1. : c;
+  double theta = acos(c);
+  if (s < 1e-5) {
+    double t;
+    if (c > 0) rx = ry = rz = 0;
+    else {
+      t = (R[0] + 1) * 0.5;
+      rx = sqrt(fmax(t, 0.));
+      t = (R[4] + 1) * 0.5;
+      ry = sqrt(fmax(t, 0.)) * (R[1] < 0 ? -1. : 1.);
+      t = (R[8] + 1) * 0.5;
+      rz = sqrt(fmax(t, 0.)) * (R[2] < 0 ? -1. : 1.);
+      if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && (R[5] > 0) != (ry * rz > 0)) rz = -rz;
+      theta /= sqrt(rx * rx + ry * ry + rz * rz);
+      rx *= theta; ry *= theta; rz *= theta;
+    }
+  } else {
+    double vth = 1 / (2 * s);
+    vth *= theta;
+    rx *= vth; ry *= vth; rz *= vth;
+  }
+  r[0] = rx; r[1] = ry; r[2] = rz;
+}
+
+__device__ inline void gm_project_point(const double R[9], const double* dRdr, const double t[3], const CamK& cam,
+                                        const double M[3], double m[2], double* dpdr, double* dpdt) {
+  double X = M[0], Y = M[1], Z = M[2];
+  double x = R[0] * X + R[1] * Y + R[2] * Z + t[0];
+  double y = R[3] * X + R[4] * Y + R[5] * Z + t[1];
+  double z = R[6] * X + R[7] * Y + R[8] * Z + t[2];
+  z = z ? 1. / z : 1;
+  x *= z; y *= z;
+  m[0] = x * cam.fx + cam.cx;
+  m[1] = y * cam.fy + cam.cy;
+  if (dpdt) {
+    double dxdt[3] = {z, 0, -x * z}, dydt[3] = {0, z, -y * z};
+    for (int j = 0; j < 3; j++) {
+      dpdt[j] = cam.fx * dxdt[j];
+      dpdt[3 + j] = cam.fy * dydt[j];
+    }
+  }
+  if (dpdr) {
+    double dx0dr[3] = {X * dRdr[0] + Y * dRdr[1] + Z * dRdr[2], X * dRdr[9] + Y * dRdr[10] + Z * dRdr[11],
+                       X * dRdr[18] + Y * dRdr[19] + Z * dRdr[20]};
+    double dy0dr[3] = {X * dRdr[3] + Y * dRdr[4] + Z * dRdr[5], X * dRdr[12] + Y * dRdr[13] + Z * dRdr[14],
+                       X * dRdr[21] + Y * dRdr[22] + Z * dRdr[23]};
+    double dz0dr[3] = {X * dRdr[6] + Y * dRdr[7] + Z * dRdr[8], X * dRdr[15] + Y * dRdr[16] + Z * dRdr[17],
+                       X * dRdr[24] + Y * dRdr[25] + Z * dRdr[26]};
+    for (int j = 0; j < 3; j++) {
+      double dxdr = z * (dx0dr[j] - x * dz0dr[j]);
+      double dydr = z * (dy0dr[j] - y * dz0dr[j]);
+      dpdr[j] = cam.fx * dxdr;
+      dpdr[3 + j] = cam.fy * dydr;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// EPnP on 5 points (epnp.cpp) — the solvePnPRansac minimal kernel
+// ---------------------------------------------------------------------------------------------------
+#define EP_N 5
+struct EpnpState {
+  double fu, fv, uc, vc;
+  double pws[3 * EP_N], us[2 * EP_N], alphas[4 * EP_N], pcs[3 * EP_N];
+  double cws[4][3], ccs[4][3];
+};
+
+__device__ __forceinline__ double ep_dot(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ double ep_dist2(const double* p1, const double* p2) {
+  return (p1[0] - p2[0]) * (p1[0] - p2[0]) + (p1[1] - p2[1]) * (p1[1] - p2[1]) + (p1[2] - p2[2]) * (p1[2] - p2[2]);
+}
+
+__device__ GL_NOINLINE void ep_qr_solve(double* pA, double* pb, double* pX, int nr, int nc) {
+  double A1[6], A2[6];
+  double* ppAkk = pA;
+  for (int k = 0; k < nc; k++) {
+    double *ppAik1 = ppAkk, eta = fabs(*ppAik1);
+    for (int i = k + 1; i < nr; i++) {
+      double elt = fabs(*ppAik1);
+      if (eta < elt) eta = elt;
+      ppAik1 += nc;
+    }
+    if (eta == 0) { A1[k] = A2[k] = 0.0; return; }
+    double *ppAik2 = ppAkk, sum2 = 0.0, inv_eta = 1. / eta;
+    for (int i = k; i < nr; i++) {
+      *ppAik2 *= inv_eta;
+      sum2 += *ppAik2 * *ppAik2;
+      ppAik2 += nc;
+    }
+    double sigma = sqrt(sum2);
+    if (*ppAkk < 0) sigma = -sigma;
+    *ppAkk += sigma;
+    A1[k] = sigma * *ppAkk;
+    A2[k] = -eta * sigma;
+    for (int j = k + 1; j < nc; j++) {
+      double *ppAik = ppAkk, sum = 0;
+      for (int i = k; i < nr; i++) { sum += *ppAik * ppAik[j - k]; ppAik += nc; }
+      double tau = sum / A1[k];
+      ppAik = ppAkk;
+      for (int i = k; i < nr; i++) { ppAik[j - k] -= tau * *ppAik; ppAik += nc; }
+    }
+    ppAkk += nc + 1;
+  }
+  double* ppAjj = pA;
+  for (int j = 0; j < nc; j++) {
+    double *ppAij = ppAjj, tau = 0;
+    for (int i = j; i < nr; i++) { tau += *ppAij * pb[i]; ppAij += nc; }
+    tau /= A1[j];
+    ppAij = ppAjj;
+    for (int i = j; i < nr; i++) { pb[i] -= tau * *ppAij; ppAij += nc; }
+    ppAjj += nc + 1;
+  }
+  pX[nc - 1] = pb[nc - 1] / A2[nc - 1];
+  for (int i = nc - 2; i >= 0; i--) {
+    double *ppAij = pA + i * nc + (i + 1), sum = 0;
+    for (int j = i + 1; j < nc; j++) { sum += *ppAij * pX[j]; ppAij++; }
+    pX[i] = (pb[i] - sum) / A2[i];
+  }
+}
+
+__device__ GL_NOINLINE void ep_gauss_newton(const double* L, const double* rho, double betas[4]) {
+  double a[24], b[6], x[4] = {0, 0, 0, 0};
+  for (int k = 0; k < 5; k++) {
+    for (int i = 0; i < 6; i++) {
+      const double* rowL = L + i * 10;
+      double* rowA = a + i * 4;
+      rowA[0] = 2 * rowL[0] * betas[0] + rowL[1] * betas[1] + rowL[3] * betas[2] + rowL[6] * betas[3];
+      rowA[1] = rowL[1] * betas[0] + 2 * rowL[2] * betas[1] + rowL[4] * betas[2] + rowL[7] * betas[3];
+      rowA[2] = rowL[3] * betas[0] + rowL[4] * betas[1] + 2 * rowL[5] * betas[2] + rowL[8] * betas[3];
+      rowA[3] = rowL[6] * betas[0] + rowL[7] * betas[1] + rowL[8] * betas[2] + 2 * rowL[9] * betas[3];
+      b[i] = rho[i] - (rowL[0] * betas[0] * betas[0] + rowL[1] * betas[0] * betas[1] + rowL[2] * betas[1] * betas[1] +
+                       rowL[3] * betas[0] * betas[2] + rowL[4] * betas[1] * betas[2] + rowL[5] * betas[2] * betas[2] +
+                       rowL[6] * betas[0] * betas[3] + rowL[7] * betas[1] * betas[3] + rowL[8] * betas[2] * betas[3] +
+                       rowL[9] * betas[3] * betas[3]);
+    }
+    ep_qr_solve(a, b, x, 6, 4);
+    for (int i = 0; i < 4; i++) betas[i] += x[i];
+  }
+}
+
+__device__ GL_NOINLINE double ep_compute_R_and_t(EpnpState& e, const double* ut, const double* betas, double R[3][3], double t[3]) {
+  const int n = EP_N;
+  for (int i = 0; i < 4; i++) e.ccs[i][0] = e.ccs[i][1] = e.ccs[i][2] = 0.0f;
+  for (int i = 0; i < 4; i++) {
+    const double* v = ut + 12 * (11 - i);
+    for (int j = 0; j < 4; j++)
+      for (int k = 0; k < 3; k++) e.ccs[j][k] += betas[i] * v[3 * j + k];
+  }
+  for (int i = 0; i < n; i++) {
+    double* a = &e.alphas[4 * i];
+    double* pc = &e.pcs[3 * i];
+    for (int j = 0; j < 3; j++) pc[j] = a[0] * e.ccs[0][j] + a[1] * e.ccs[1][j] + a[2] * e.ccs[2][j] + a[3] * e.ccs[3][j];
+  }
+  if (e.pcs[2] < 0.0) {
+    for (int i = 0; i < 4; i++)
+      for (int j = 0; j < 3; j++) e.ccs[i][j] = -e.ccs[i][j];
+    for (int i = 0; i < n; i++) { e.pcs[3 * i] = -e.pcs[3 * i]; e.pcs[3 * i + 1] = -e.pcs[3 * i + 1]; e.pcs[3 * i + 2] = -e.pcs[3 * i + 2]; }
+  }
+  // estimate_R_and_t
+  double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0};
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < 3; j++) { pc0[j] += e.pcs[3 * i + j]; pw0[j] += e.pws[3 * i + j]; }
+  for (int j = 0; j < 3; j++) { pc0[j] /= n; pw0[j] /= n; }
+  double abt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, abt_d[3], abt_u[9], abt_vt[9], abt_v[9];
+  for (int i = 0; i < n; i++) {
+    double* pc = &e.pcs[3 * i];
+    double* pw = &e.pws[3 * i];
+    for (int j = 0; j < 3; j++) {
+      abt[3 * j] += (pc[j] - pc0[j]) * (pw[0] - pw0[0]);
+      abt[3 * j + 1] += (pc[j] - pc0[j]) * (pw[1] - pw0[1]);
+      abt[3 * j + 2] += (pc[j] - pc0[j]) * (pw[2] - pw0[2]);
+    }
+  }
+  gl_svd3(abt, abt_d, abt_u, abt_vt);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) abt_v[i * 3 + j] = abt_vt[j * 3 + i];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) R[i][j] = ep_dot(abt_u + 3 * i, abt_v + 3 * j);
+  const double det = R[0][0] * R[1][1] * R[2][2] + R[0][1] * R[1][2] * R[2][0] + R[0][2] * R[1][0] * R[2][1] -
+                     R[0][2] * R[1][1] * R[2][0] - R[0][1] * R[1][0] * R[2][2] - R[0][0] * R[1][2] * R[2][1];
+  if (det < 0) { R[2][0] = -R[2][0]; R[2][1] = -R[2][1]; R[2][2] = -R[2][2]; }
+  t[0] = pc0[0] - ep_dot(R[0], pw0);
+  t[1] = pc0[1] - ep_dot(R[1], pw0);
+  t[2] = pc0[2] - ep_dot(R[2], pw0);
+  // reprojection_error
+  double sum2 = 0.0;
+  for (int i = 0; i < n; i++) {
+    double* pw = &e.pws[3 * i];
+    double Xc = ep_dot(R[0], pw) + t[0];
+    double Yc = ep_dot(R[1], pw) + t[1];
+    double inv_Zc = 1.0 / (ep_dot(R[2], pw) + t[2]);
+    double ue = e.uc + e.fu * Xc * inv_Zc;
+    double ve = e.vc + e.fv * Yc * inv_Zc;
+    double u = e.us[2 * i], v = e.us[2 * i + 1];
+    sum2 += sqrt((u - ue) * (u - ue) + (v - ve) * (v - ve));
+  }
+  return sum2 / n;
+}
+
+// solvePnP(SOLVEPNP_EPNP) for 5 float correspondences -> rvec, tvec
+__device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const CamK& cam, double rvec[3], double tvec[3]) {
+  const int n = EP_N;
+  EpnpState e;
+  e.fu = cam.fx; e.fv = cam.fy; e.uc = cam.cx; e.vc = cam.cy;
+  double ifx = 1. / cam.fx, ify = 1. / cam.fy;
+  for (int i = 0; i < n; i++) {
+    e.pws[3 * i] = obj[3 * i]; e.pws[3 * i + 1] = obj[3 * i + 1]; e.pws[3 * i + 2] = obj[3 * i + 2];
+    float xn = (float)(((double)img[2 * i] - cam.cx) * ifx);
+    float yn = (float)(((double)img[2 * i + 1] - cam.cy) * ify);
+    e.us[2 * i] = xn * e.fu + e.uc;
+    e.us[2 * i + 1] = yn * e.fv + e.vc;
+  }
+  // choose_control_points
+  e.cws[0][0] = e.cws[0][1] = e.cws[0][2] = 0;
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < 3; j++) e.cws[0][j] += e.pws[3 * i + j];
+  for (int j = 0; j < 3; j++) e.cws[0][j] /= n;
+  {
+    double pw0[3 * EP_N];
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < 3; j++) pw0[3 * i + j] = e.pws[3 * i + j] - e.cws[0][j];
+    double pw0tpw0[9], dc[3], U[9];
+    for (int a = 0; a < 3; a++)
+      for (int b = a; b < 3; b++) {
+        double s = 0;
+        for (int i = 0; i < n; i++) s += pw0[3 * i + a] * pw0[3 * i + b];
+        pw0tpw0[a * 3 + b] = pw0tpw0[b * 3 + a] = s;
+      }
+    gl_svd3(pw0tpw0, dc, U, nullptr);
+    for (int i = 1; i < 4; i++) {
+      double k = sqrt(dc[i - 1] / n);
+      for (int j = 0; j < 3; j++) e.cws[i][j] = e.cws[0][j] + k * U[j * 3 + (i - 1)];  // uct[3*(i-1)+j] = U[j][i-1]
+    }
+  }
+  // compute_barycentric_coordinates
+  {
+    double cc[9], ci[9];
+    for (int i = 0; i < 3; i++)
+      for (int j = 1; j < 4; j++) cc[3 * i + j - 1] = e.cws[j][i] - e.cws[0][i];
+    gl_invert3_svd(cc, ci);
+    for (int i = 0; i < n; i++) {
+      double* pi = &e.pws[3 * i];
+      double* a = &e.alphas[4 * i];
+      for (int j = 0; j < 3; j++)
+        a[1 + j] = ci[3 * j] * (pi[0] - e.cws[0][0]) + ci[3 * j + 1] * (pi[1] - e.cws[0][1]) + ci[3 * j + 2] * (pi[2] - e.cws[0][2]);
+      a[0] = 1.0f - a[1] - a[2] - a[3];
+    }
+  }
+  // M (2n x 12), MtM, SVD
+  double ut[144];
+  {
+    double M[2 * EP_N * 12];
+    for (int i = 0; i < n; i++) {
+      const double* as = &e.alphas[4 * i];
+      double u = e.us[2 * i], v = e.us[2 * i + 1];
+      double* M1 = &M[(2 * i) * 12];
+      double* M2 = M1 + 12;
+      for (int k = 0; k < 4; k++) {
+        M1[3 * k] = as[k] * e.fu; M1[3 * k + 1] = 0.0; M1[3 * k + 2] = as[k] * (e.uc - u);
+        M2[3 * k] = 0.0; M2[3 * k + 1] = as[k] * e.fv; M2[3 * k + 2] = as[k] * (e.vc - v);
+      }
+    }
+    double mtm[144], d[12], tv[144];
+    for (int a = 0; a < 12; a++)
+      for (int b = a; b < 12; b++) {
+        double s = 0;
+        for (int i = 0; i < 2 * n; i++) s += M[i * 12 + a] * M[i * 12 + b];
+        mtm[a * 12 + b] = mtm[b * 12 + a] = s;
+      }
+    // Ut rows = left singular vectors = rows of the rotated A^T: run the one-sided Jacobi directly on mtm^T
+    for (int i = 0; i < 12; i++)
+      for (int j = i + 1; j < 12; j++) { double t = mtm[i * 12 + j]; mtm[i * 12 + j] = mtm[j * 12 + i]; mtm[j * 12 + i] = t; }
+    gl_jacobi_svd(mtm, 12, d, tv, 12, 12, 12);
+    for (int i = 0; i < 144; i++) ut[i] = mtm[i];
+  }
+  double l_6x10[60], rho[6];
+  {
+    const double* v[4] = {ut + 12 * 11, ut + 12 * 10, ut + 12 * 9, ut + 12 * 8};
+    double dv[4][6][3];
+    for (int i = 0; i < 4; i++) {
+      int a = 0, b = 1;
+      for (int j = 0; j < 6; j++) {
+        dv[i][j][0] = v[i][3 * a] - v[i][3 * b];
+        dv[i][j][1] = v[i][3 * a + 1] - v[i][3 * b + 1];
+        dv[i][j][2] = v[i][3 * a + 2] - v[i][3 * b + 2];
+        b++;
+        if (b > 3) { a++; b = a + 1; }
+      }
+    }
+    for (int i = 0; i < 6; i++) {
+      double* row = l_6x10 + 10 * i;
+      row[0] = ep_dot(dv[0][i], dv[0][i]);
+      row[1] = 2.0f * ep_dot(dv[0][i], dv[1][i]);
+      row[2] = ep_dot(dv[1][i], dv[1][i]);
+      row[3] = 2.0f * ep_dot(dv[0][i], dv[2][i]);
+      row[4] = 2.0f * ep_dot(dv[1][i], dv[2][i]);
+      row[5] = ep_dot(dv[2][i], dv[2][i]);
+      row[6] = 2.0f * ep_dot(dv[0][i], dv[3][i]);
+      row[7] = 2.0f * ep_dot(dv[1][i], dv[3][i]);
+      row[8] = 2.0f * ep_dot(dv[2][i], dv[3][i]);
+      row[9] = ep_dot(dv[3][i], dv[3][i]);
+    }
+    rho[0] = ep_dist2(e.cws[0], e.cws[1]); rho[1] = ep_dist2(e.cws[0], e.cws[2]); rho[2] = ep_dist2(e.cws[0], e.cws[3]);
+    rho[3] = ep_dist2(e.cws[1], e.cws[2]); rho[4] = ep_dist2(e.cws[1], e.cws[3]); rho[5] = ep_dist2(e.cws[2], e.cws[3]);
+  }
+  double Betas[4][4], rep_errors[4] = {0, 0, 0, 0};
+  double Rs[4][3][3], ts[4][3];
+  {  // find_betas_approx_1
+    double l[24], b4[4];
+    for (int i = 0; i < 6; i++) { l[i * 4] = l_6x10[i * 10]; l[i * 4 + 1] = l_6x10[i * 10 + 1]; l[i * 4 + 2] = l_6x10[i * 10 + 3]; l[i * 4 + 3] = l_6x10[i * 10 + 6]; }
+    gl_solve_svd(l, 6, 4, rho, b4);
+    double* betas = Betas[1];
+    if (b4[0] < 0) { betas[0] = sqrt(-b4[0]); betas[1] = -b4[1] / betas[0]; betas[2] = -b4[2] / betas[0]; betas[3] = -b4[3] / betas[0]; }
+    else { betas[0] = sqrt(b4[0]); betas[1] = b4[1] / betas[0]; betas[2] = b4[2] / betas[0]; betas[3] = b4[3] / betas[0]; }
+  }
+  ep_gauss_newton(l_6x10, rho, Betas[1]);
+  rep_errors[1] = ep_compute_R_and_t(e, ut, Betas[1], Rs[1], ts[1]);
+  {  // find_betas_approx_2
+    double l[18], b3[3];
+    for (int i = 0; i < 6; i++) { l[i * 3] = l_6x10[i * 10]; l[i * 3 + 1] = l_6x10[i * 10 + 1]; l[i * 3 + 2] = l_6x10[i * 10 + 2]; }
+    gl_solve_svd(l, 6, 3, rho, b3);
+    double* betas = Betas[2];
+    if (b3[0] < 0) { betas[0] = sqrt(-b3[0]); betas[1] = (b3[2] < 0) ? sqrt(-b3[2]) : 0.0; }
+    else { betas[0] = sqrt(b3[0]); betas[1] = (b3[2] > 0) ? sqrt(b3[2]) : 0.0; }
+    if (b3[1] < 0) betas[0] = -betas[0];
+    betas[2] = 0.0; betas[3] = 0.0;
+  }
+  ep_gauss_newton(l_6x10, rho, Betas[2]);
+  rep_errors[2] = ep_compute_R_and_t(e, ut, Betas[2], Rs[2], ts[2]);
+  {  // find_betas_approx_3
+    double l[30], b5[5];
+    for (int i = 0; i < 6; i++)
+      for (int j = 0; j < 5; j++) l[i * 5 + j] = l_6x10[i * 10 + j];
+    gl_solve_svd(l, 6, 5, rho, b5);
+    double* betas = Betas[3];
+    if (b5[0] < 0) { betas[0] = sqrt(-b5[0]); betas[1] = (b5[2] < 0) ? sqrt(-b5[2]) : 0.0; }
+    else { betas[0] = sqrt(b5[0]); betas[1] = (b5[2] > 0) ? sqrt(b5[2]) : 0.0; }
+    if (b5[1] < 0) betas[0] = -betas[0];
+    betas[2] = b5[3] / betas[0];
+    betas[3] = 0.0;
+  }
+  ep_gauss_newton(l_6x10, rho, Betas[3]);
+  rep_errors[3] = ep_compute_R_and_t(e, ut, Betas[3], Rs[3], ts[3]);
+  int N = 1;
+  if (rep_errors[2] < rep_errors[1]) N = 2;
+  if (rep_errors[3] < rep_errors[N]) N = 3;
+  double R[9];
+  for (int i = 0; i < 3; i++) {
+    tvec[i] = ts[N][i];
+    for (int j = 0; j < 3; j++) R[i * 3 + j] = Rs[N][i][j];
+  }
+  gm_rodrigues_m2v(R, rvec);
+}
+
+struct PnPModel {
+  static constexpr int MP = 5, MAXM = 1, MS = 6, PT1 = 3, PT2 = 2;
+  __device__ static bool check_subset(const float*, const float*) { return true; }
+  __device__ static int solve(const ModelParams& P, const float* ms1, const float* ms2, double* model) {
+    double rvec[3], tvec[3];
+    gm_epnp5(ms1, ms2, P.cam, rvec, tvec);
+    for (int i = 0; i < 3; i++) { model[2 * i] = rvec[i]; model[2 * i + 1] = tvec[i]; }  // hconcat(rvec, tvec)
+    return 1;
+  }
+  struct Scorer {
+    double R[9], t[3];
+    CamK cam;
+    __device__ void init(const ModelParams& P, const double* model) {
+      double rvec[3] = {model[0], model[2], model[4]};
+      t[0] = model[1]; t[1] = model[3]; t[2] = model[5];
+      gm_rodrigues_v2m(rvec, R, nullptr);
+      cam = P.cam;
+    }
+    __device__ __forceinline__ float err(const float* M3, const float* m2) const {
+      double M[3] = {M3[0], M3[1], M3[2]}, m[2];
+      gm_project_point(R, nullptr, t, cam, M, m, nullptr, nullptr);
+      float px = (float)m[0], py = (float)m[1];
+      float dx = m2[0] - px, dy = m2[1] - py;
+      float s = 0;
+      s += dx * dx;
+      s += dy * dy;
+      return s;
+    }
+  };
+};

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs A) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int slot = blockIdx.y;
   const int p = blockIdx.x * 4 + wave;
-  if (p >= A.npts[slot]) return;  // wave-uniform
+  if (p >= min(A.npts[slot], A.maxpts)) return;  // wave-uniform
   LkWaveLds& S = lds[wave];
   const size_t pidx = (size_t)slot * A.maxpts + p;
   const float ptx = A.prev_pts[2 * pidx], pty = A.prev_pts[2 * pidx + 1];
@@ -383,7 +383,9 @@ extern "C" int mvo_lk_track(mvo_ctx* ctx, const uint8_t* prev, const uint8_t* ne
   lk_build_pyramid(ctx, 0, L, 1);
   lk_build_pyramid(ctx, 1, L, 1);
   MVO_HIP(hipMemcpyAsync(ctx->d_prev_pts, prev_pts, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-  MVO_HIP(hipMemcpyAsync(ctx->d_npts, &n, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  int* hn = (int*)ctx->h_pin;
+  hn[0] = n;
+  MVO_HIP(hipMemcpyAsync(ctx->d_npts, hn, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   lk_track_device(ctx, 0, 1, L, 1, n);
   MVO_HIP(hipMemcpyAsync(next_pts, ctx->d_next_pts, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   MVO_HIP(hipMemcpyAsync(status, ctx->d_status, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void hamming_knn2_kernel(const u8* __restrict_
                                                            unsigned* __restrict__ best, int cap) {
   __shared__ uint4 s_t[MT_TILE * 2];
   const int slot = blockIdx.y;
-  const int nq = nq_[slot], nt = nt_[slot];
+  const int nq = min(nq_[slot], cap), nt = min(nt_[slot], cap);
   const int qi = blockIdx.x * 256 + threadIdx.x;
   if (blockIdx.x * 256 >= nq) return;  // block-uniform
   const uint4* qp = (const uint4*)(q + ((size_t)slot * cap + (qi < nq ? qi : 0)) * 32);
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(1024) void ratio_compact_kernel(const unsigned* __r
   __shared__ int s_wave[16];
   __shared__ int s_base;
   const int slot = blockIdx.x;
-  const int nq = nq_[slot];
+  const int nq = min(nq_[slot], cap);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) s_base = 0;
   __syncthreads();
@@ -136,12 +136,14 @@ extern "C" int mvo_match_knn2_ratio(mvo_ctx* ctx, const uint8_t* q, int nq, cons
   if (nq > m->cap || nt > m->cap || nt > 65535) { ctx->set_error("mvo_match_knn2_ratio: capacity"); return MVO_E_CAPACITY; }
   MVO_HIP(hipMemcpyAsync(m->d_q, q, (size_t)nq * 32, hipMemcpyHostToDevice, ctx->stream));
   MVO_HIP(hipMemcpyAsync(m->d_t, t, (size_t)nt * 32, hipMemcpyHostToDevice, ctx->stream));
-  MVO_HIP(hipMemcpyAsync(m->d_nq, &nq, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-  MVO_HIP(hipMemcpyAsync(m->d_nt, &nt, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  int* hn = (int*)ctx->h_pin;
+  hn[0] = nq; hn[1] = nt;
+  MVO_HIP(hipMemcpyAsync(m->d_nq, hn, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  MVO_HIP(hipMemcpyAsync(m->d_nt, hn + 1, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   match_device(ctx, 1, nq, ratio);
-  int cnt = 0;
-  MVO_HIP(hipMemcpyAsync(&cnt, m->d_nout, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  MVO_HIP(hipMemcpyAsync(hn + 2, m->d_nout, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   MVO_HIP(hipStreamSynchronize(ctx->stream));
+  int cnt = hn[2];
   *n = cnt;
   int ncopy = cnt < cap ? cnt : cap;
   if (ncopy > 0) {

@@ -742,9 +742,10 @@ extern "C" int mvo_fast9_nms(mvo_ctx* ctx, const uint8_t* img, int w, int h, int
   hipLaunchKernelGGL(scan_slots_kernel, dim3(1), dim3(64), 0, st, o->d_slot_tot, o->d_slot_base, 1);
   hipLaunchKernelGGL(nms_rows_kernel<1>, g2, dim3(256), 0, st, o->d_score, G, o->d_row_cnt, o->d_row_off, o->d_slot_base,
                      o->max_rows, o->d_cx, o->d_cy, o->d_cs, o->d_cl, o->d_cslot, o->cand_cap);
-  int total = 0;
-  MVO_HIP(hipMemcpyAsync(&total, o->d_slot_tot, sizeof(int), hipMemcpyDeviceToHost, st));
+  int* hn = (int*)ctx->h_pin;
+  MVO_HIP(hipMemcpyAsync(hn, o->d_slot_tot, sizeof(int), hipMemcpyDeviceToHost, st));
   MVO_HIP(hipStreamSynchronize(st));
+  int total = hn[0];
   *n = total;
   if (total > o->cand_cap) { ctx->set_error("FAST candidate capacity exceeded"); return MVO_E_CAPACITY; }
   int m = total < cap ? total : cap;

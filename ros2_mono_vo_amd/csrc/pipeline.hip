@@ -322,9 +322,10 @@ extern "C" int mvo_batch_seed(mvo_ctx* ctx, int frame_idx, int* n_keypoints) {
 
 extern "C" int mvo_batch_get_tracks(mvo_ctx* ctx, int slot, float* pts, int cap, int* n) {
   if (!ctx || !ctx->pipe || !n || slot < 0 || slot >= ctx->B) return MVO_E_ARG;
-  int cnt = 0;
-  MVO_HIP(hipMemcpyAsync(&cnt, ctx->d_npts + slot, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  int* hn = (int*)ctx->h_pin;
+  MVO_HIP(hipMemcpyAsync(hn, ctx->d_npts + slot, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   MVO_HIP(hipStreamSynchronize(ctx->stream));
+  int cnt = hn[0];
   *n = cnt;
   int m = cnt < cap ? cnt : cap;
   if (m > 0 && pts) {

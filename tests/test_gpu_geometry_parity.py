@@ -1,0 +1,103 @@
+"""GPU parity: RANSAC H / F, PnP-RANSAC, triangulation, recoverPose vs the CPU oracle on SURVEY 8(d)
+geometry sets.  Inlier masks / index lists / counts bit-exact; H, F models and triangulated points
+bit-exact (same IEEE sequence per lane); PnP R,t within 1e-9 (block reductions reorder the LM sums) —
+the contract tolerance is 1e-4 relative."""
+import numpy as np
+import pytest
+
+import oracle_py as O
+from ros2_mono_vo_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def scene(P, planar=False, **kw):
+    return synth.gen_scene(P, 0xC0FFEE00 + P, planar=planar, **kw)
+
+
+@pytest.mark.parametrize("P,planar", [(200, False), (1000, False), (2000, False), (4000, False), (2000, True)])
+def test_homography_mask_bitexact(ctx720, P, planar):
+    sc = scene(P, planar)
+    ok, mask, H, ni = ctx720.find_homography_ransac(sc["p1"], sc["p2"], 1.0)
+    r, omask, oH, st = O.find_homography_ransac(sc["p1"], sc["p2"], 1.0)
+    assert ok == (r > 0)
+    assert np.array_equal(mask, omask) and ni == r
+    assert np.array_equal(H, oH)
+    if planar:
+        assert mask[~sc["inlier"]].sum() <= 2 and ni > 0.4 * sc["inlier"].sum()
+
+
+@pytest.mark.parametrize("P,planar", [(200, False), (1000, False), (2000, False), (4000, False), (2000, True)])
+def test_fundamental_mask_bitexact(ctx720, P, planar):
+    sc = scene(P, planar)
+    ok, mask, F, ni = ctx720.find_fundamental_ransac(sc["p1"], sc["p2"], 1.0, 0.99)
+    r, omask, oF, st = O.find_fundamental_ransac(sc["p1"], sc["p2"], 1.0, 0.99)
+    assert ok == (r > 0)
+    assert np.array_equal(mask, omask) and ni == r
+    assert np.abs(F - oF).max() <= 1e-12 * max(1.0, np.abs(oF).max())
+    if not planar:
+        assert mask[~sc["inlier"]].sum() <= 0.02 * P
+
+
+def test_ransac_edge_cases(ctx720):
+    sc = scene(200)
+    # exactly the minimal sample: single solve, mask all ones
+    ok, mask, H, ni = ctx720.find_homography_ransac(sc["p1"][:4], sc["p2"][:4])
+    r, omask, oH, _ = O.find_homography_ransac(sc["p1"][:4], sc["p2"][:4])
+    assert ok and mask.all() and np.array_equal(H, oH)
+    ok, mask, F, ni = ctx720.find_fundamental_ransac(sc["p1"][:7], sc["p2"][:7])
+    assert ok and mask.all() and ni == 7
+    # fewer than 7 points: empty result (reference: countNonZero(empty) == 0)
+    ok, mask, F, ni = ctx720.find_fundamental_ransac(sc["p1"][:6], sc["p2"][:6])
+    assert not ok and ni == 0
+    # all points identical -> degenerate
+    z = np.ones((50, 2), np.float32)
+    ok, mask, H, ni = ctx720.find_homography_ransac(z, z)
+    r, omask, _, _ = O.find_homography_ransac(z, z)
+    assert ok == (r > 0) and np.array_equal(mask, omask)
+    # forced 4096 hypotheses (C4: LDS-pressure config): confidence ~1 disables the early stop
+    sc = scene(4000)
+    ok, mask, H, ni = ctx720.find_homography_ransac(sc["p1"], sc["p2"], 1.0, 4096, 1 - 1e-15)
+    r, omask, oH, st = O.find_homography_ransac(sc["p1"], sc["p2"], 1.0, 4096, 1 - 1e-15)
+    assert st[0] == 4096 and np.array_equal(mask, omask) and np.array_equal(H, oH)
+
+
+@pytest.mark.parametrize("P,planar", [(200, False), (1000, False), (2000, False), (4000, False), (1000, True)])
+def test_pnp_ransac(ctx720, P, planar):
+    sc = scene(P, planar)
+    ok, r, t, idx = ctx720.solve_pnp_ransac(sc["X"], sc["p2"], sc["K"])
+    rc, orv, otv, oidx, st = O.solve_pnp_ransac(sc["X"], sc["p2"], sc["K"])
+    assert ok and rc == 1
+    assert np.array_equal(idx, oidx)                       # inlier index list bit-exact
+    tol = 1e-9
+    assert np.abs(r - orv).max() <= tol * max(1.0, np.abs(orv).max())
+    assert np.abs(t - otv).max() <= tol * max(1.0, np.abs(otv).max())
+    # and against the planted ground truth (noise-limited)
+    Rgt = sc["R"]
+    assert np.abs(O.rodrigues(r) - Rgt).max() < 2e-3 and np.abs(t - sc["t"]).max() < 5e-2
+
+
+def test_triangulate_bitexact(ctx720):
+    sc = scene(2000)
+    K = sc["K"]
+    P1 = K @ np.hstack([np.eye(3), np.zeros((3, 1))])
+    P2 = K @ np.hstack([sc["R"], sc["t"][:, None]])
+    g = ctx720.triangulate(P1, P2, sc["p1"], sc["p2"])
+    o, _ = O.triangulate(P1, P2, sc["p1"], sc["p2"])
+    assert np.array_equal(g, o)
+
+
+def test_recover_pose(ctx720):
+    sc = scene(2000)
+    t = sc["t"]
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    E = tx @ sc["R"]
+    m0 = sc["inlier"].astype(np.uint8)
+    g, R, tt, m = ctx720.recover_pose(E, sc["p1"], sc["p2"], sc["K"], mask=m0)
+    og, oR, ot, om = O.recover_pose(E, sc["p1"], sc["p2"], sc["K"], mask=m0)
+    assert g == og and np.array_equal(m, om)
+    assert np.array_equal(R, oR) and np.array_equal(tt, ot)
+    assert np.abs(R - sc["R"]).max() < 1e-9
+    # the three wrong candidates must lose: flipped E sign still recovers the same pose
+    g2, R2, t2, _ = ctx720.recover_pose(-E, sc["p1"], sc["p2"], sc["K"], mask=m0)
+    assert np.abs(R2 - sc["R"]).max() < 1e-9
