@@ -34,27 +34,28 @@ def make_streams(w, h, n_frames, n_distinct, seed0):
     return [synth.gen_stream(w, h, seed0 + 1 + i, n_frames) for i in range(n_distinct)]
 
 
-def cpu_baseline(streams, nfeatures, n_frames, stages_on):
+def planar_landmarks(K, z=10.0):
+    def f(xy):
+        zz = np.full(len(xy), z, np.float32)
+        return np.stack([(xy[:, 0] - K[0, 2]) / K[0, 0] * zz, (xy[:, 1] - K[1, 2]) / K[1, 1] * zz, zz], 1)
+    return f
+
+
+def cpu_baseline(streams, K, nfeatures, n_frames):
     """The oracle (CPU restatement, 1 thread) on a bounded sample of the same workload: stream 0,
-    `n_frames` consecutive steps of the same stage list.  Test infrastructure used as the checker/baseline
-    only — never on the product path."""
-    import oracle_py as O
+    `n_frames` consecutive full steps (tests/pipeline_ref.py: the same stage list and data flow as
+    mvo_batch_step).  Test infrastructure used as the baseline only — never on the product path."""
+    from pipeline_ref import StreamRef
     fr = streams[0]
-    t0 = time.perf_counter()
-    kps, desc = O.orb_detect_and_compute(fr[0], nfeatures)
-    pts = np.stack([kps["x"], kps["y"]], 1)
-    t_seed = time.perf_counter() - t0
+    ref = StreamRef(K, nfeatures)
+    ref.seed(fr[0], planar_landmarks(K))
     t0 = time.perf_counter()
     done = 0
     for k in range(1, min(n_frames + 1, len(fr))):
-        O.lk_track(fr[k - 1], fr[k], pts, cn=3)
-        k2, d2 = O.orb_detect_and_compute(fr[k], nfeatures)
-        O.match_knn2_ratio(desc, d2, 0.7)
-        kps, desc = k2, d2
-        pts = np.stack([kps["x"], kps["y"]], 1)
+        ref.step(fr[k])
         done += 1
     dt = time.perf_counter() - t0
-    return done / dt, done, t_seed
+    return done / dt, done
 
 
 def main():
@@ -68,7 +69,7 @@ def main():
     ap.add_argument("--nfeatures", type=int, default=2000)
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic streams generated per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=12)
+    ap.add_argument("--cpu-frames", type=int, default=10)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -106,15 +107,12 @@ def main():
     ctx.sync()
     nk = ctx.batch_seed(0)
     # planar landmarks (Z = 10 m) for the seeded tracks: the similarity-warp stream is a fronto-parallel plane
+    lmf = planar_landmarks(Kmat)
     for s in range(B):
-        p = ctx.batch_get_tracks(s)
-        z = np.full(len(p), 10.0, np.float32)
-        xyz = np.stack([(p[:, 0] - Kmat[0, 2]) / Kmat[0, 0] * z, (p[:, 1] - Kmat[1, 2]) / Kmat[1, 1] * z, z], 1)
-        ctx.batch_set_landmarks(s, xyz)
+        ctx.batch_set_landmarks(s, lmf(ctx.batch_get_tracks(s)))
 
-    stages_have = _lib.STAGE_LK | _lib.STAGE_ORB | _lib.STAGE_MATCH
-    stages_missing = ["pnp_ransac", "ransac_h", "ransac_f", "triangulate"]
-    stages = stages_have
+    stages = _lib.STAGE_ALL
+    stages_missing = []
 
     for k in range(Wm):
         ctx.batch_step(1 + k, stages)
@@ -158,14 +156,19 @@ def main():
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/i32 fixed-point + f32/f64", "data": "synthetic",
-            "config": {"workload": f"C3: {W}x{H} mono8, {args.nfeatures} ORB + LK + match; batch of {B} independent "
-                                   f"streams per GPU, key-frame branch every frame",
+            "config": {"workload": f"C3: {W}x{H} mono8, {args.nfeatures} ORB + LK + PnP-RANSAC + H/F-RANSAC + match + "
+                                   f"triangulate; batch of {B} independent streams per GPU, key-frame branch every frame",
                        "batch_per_gpu": B, "width": W, "height": H, "nfeatures": args.nfeatures,
-                       "stages": ["lk_pyramid", "lk_track", "lk_filter", "orb_detect", "orb_describe", "match"],
+                       "stages": ["lk_pyramid", "lk_track", "lk_filter", "pnp_ransac+refine", "ransac_h", "ransac_f",
+                                  "orb_detect", "orb_describe", "match", "triangulate+landmark_handover"],
                        "stages_missing": stages_missing, "parallelism": f"streams x{world}",
                        "mean_tracks_per_frame": round(lk_points / max(B * K, 1), 1),
                        "mean_keypoints": float(np.mean([r.n_keypoints for r in last])),
-                       "mean_matches": float(np.mean([r.n_matches for r in last]))},
+                       "mean_matches": float(np.mean([r.n_matches for r in last])),
+                       "mean_pnp_inliers": float(np.mean([r.n_pnp_inliers for r in last])),
+                       "mean_score_h": float(np.mean([r.score_h for r in last])),
+                       "mean_score_f": float(np.mean([r.score_f for r in last])),
+                       "mean_triangulated": float(np.mean([r.n_triangulated for r in last]))},
             "roofline": {"bound": "hbm", "kernel": "lk_track_kernel", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": None,
@@ -173,10 +176,10 @@ def main():
             "stage_ms": prof,
         }
         if not args.no_cpu_baseline:
-            fps, nfr, _ = cpu_baseline(streams, args.nfeatures, args.cpu_frames, stages)
+            fps, nfr = cpu_baseline(streams, Kmat, args.nfeatures, args.cpu_frames)
             line["cpu_baseline"] = {"value": round(fps, 3), "unit": "frames/s", "cores": 1, "kind": "port",
                                     "sample": f"oracle (CPU restatement of OpenCV-4.6 semantics, not OpenCV), stream 0, "
-                                              f"{nfr} consecutive steps of the same stage list, 1 thread"}
+                                              f"{nfr} consecutive full steps (same stage list and data flow), 1 thread"}
         print(json.dumps(line), flush=True)
     ctx.close()
     if dist is not None:

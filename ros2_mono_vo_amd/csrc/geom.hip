@@ -24,26 +24,6 @@
 
 #include <cstdlib>
 
-struct GeomState {
-  float* d_m1 = nullptr;   // [B][maxpts][3]
-  float* d_m2 = nullptr;   // [B][maxpts][2]
-  int* d_n = nullptr;      // [B]
-  u8* d_mask = nullptr;    // [B][maxpts]
-  double* d_model = nullptr;  // [B][16]
-  int* d_result = nullptr;    // [B][8]
-  // PnP refine
-  int* d_inl = nullptr;       // [B][maxpts] inlier indices
-  double* d_pose = nullptr;   // [B][8] rvec, tvec
-  float* d_x3 = nullptr;      // [B][maxpts][3]
-  // second set for running H and F side by side in the pipeline
-  u8* d_mask2 = nullptr;
-  double* d_model2 = nullptr;
-  int* d_result2 = nullptr;
-  double* d_tmp = nullptr;    // 64 doubles of scratch
-  double* h_model = nullptr;  // pinned
-  int* h_result = nullptr;
-};
-
 struct RansacArgs {
   const float* m1;
   const float* m2;
@@ -695,8 +675,8 @@ int geom_state_create(mvo_ctx* ctx) {
   MVO_HIP(hipMalloc(&g->d_pose, (size_t)ctx->B * 8 * sizeof(double)));
   MVO_HIP(hipMalloc(&g->d_x3, np * 3 * sizeof(float)));
   MVO_HIP(hipMalloc(&g->d_tmp, 64 * sizeof(double)));
-  MVO_HIP(hipHostMalloc(&g->h_model, (size_t)ctx->B * 16 * sizeof(double) * 3, hipHostMallocDefault));
-  MVO_HIP(hipHostMalloc(&g->h_result, (size_t)ctx->B * 8 * sizeof(int) * 3, hipHostMallocDefault));
+  MVO_HIP(hipHostMalloc(&g->h_model, ((size_t)ctx->B * 16 + 64) * sizeof(double) * 3, hipHostMallocDefault));
+  MVO_HIP(hipHostMalloc(&g->h_result, ((size_t)ctx->B * 8 + 16) * sizeof(int) * 4, hipHostMallocDefault));
   MVO_HIP(hipMemsetAsync(g->d_result, 0, (size_t)ctx->B * 8 * sizeof(int), ctx->stream));
   MVO_HIP(hipMemsetAsync(g->d_result2, 0, (size_t)ctx->B * 8 * sizeof(int), ctx->stream));
   return MVO_OK;
@@ -763,7 +743,74 @@ int geom_pnp(mvo_ctx* ctx, int nslots, const float* obj, const float* img, const
   return MVO_OK;
 }
 
-int pipe_geometry_stages(mvo_ctx*, unsigned, mvo_step_result*) { return MVO_OK; }
+
+// ---- batched triangulation of key-frame <-> current matches (Tracker::triangulate_points, src/tracker.cpp:138-180) ----
+// P = K [R|t] per view from the device-resident poses (rvec, tvec of T_cw); cheirality as the reference:
+// p3d (float) transformed by both T_cw in double, rounded to float, z > 0 in both.
+struct TriBatchArgs {
+  const mvo_match* matches;  // [B][cap]
+  const int* n_matches;      // [B]
+  const float* kf_xy;        // [B][cap][2]  key-frame key-point positions (match query side)
+  const float* cur_xy;       // [B][cap][2]  current key-point positions (match train side)
+  const double* kf_pose;     // [B][8] rvec, tvec (T_cw)
+  const double* cur_pose;    // [B][8]
+  const int* pnp_result;     // [B][8] (slot valid iff [0] && [6]) or null
+  CamK cam;
+  int cap;
+  float* X3;   // [B][cap][3]
+  u8* valid;   // [B][cap]
+};
+
+__global__ __launch_bounds__(256) void triangulate_matches_kernel(TriBatchArgs A) {
+  __shared__ double s_P[2][12];
+  __shared__ double s_T[2][12];
+  const int slot = blockIdx.y;
+  const int n = min(max(A.n_matches[slot], 0), A.cap);
+  if (blockIdx.x * 256 >= n) return;
+  bool pose_ok = true;
+  if (A.pnp_result) pose_ok = A.pnp_result[slot * 8] && A.pnp_result[slot * 8 + 6];
+  if (threadIdx.x < 2) {
+    const double* pose = (threadIdx.x == 0 ? A.kf_pose : A.cur_pose) + (size_t)slot * 8;
+    double R[9];
+    gm_rodrigues_v2m(pose, R, nullptr);
+    double E[12] = {R[0], R[1], R[2], pose[3], R[3], R[4], R[5], pose[4], R[6], R[7], R[8], pose[5]};
+    const double Km[9] = {A.cam.fx, 0, A.cam.cx, 0, A.cam.fy, A.cam.cy, 0, 0, 1};
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 4; j++) {
+        s_P[threadIdx.x][i * 4 + j] = Km[i * 3] * E[j] + Km[i * 3 + 1] * E[4 + j] + Km[i * 3 + 2] * E[8 + j];
+        s_T[threadIdx.x][i * 4 + j] = E[i * 4 + j];
+      }
+  }
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const size_t b = (size_t)slot * A.cap;
+  const mvo_match m = A.matches[b + i];
+  const float* pr = A.kf_xy + 2 * (b + m.query_idx);
+  const float* pc = A.cur_xy + 2 * (b + m.train_idx);
+  double X[4];
+  gm_triangulate_one(s_P[0], s_P[1], pr[0], pr[1], pc[0], pc[1], X);
+  float xf[4] = {(float)X[0], (float)X[1], (float)X[2], (float)X[3]};
+  float scale = xf[3] != 0.f ? 1.f / xf[3] : 1.f;
+  float px = xf[0] * scale, py = xf[1] * scale, pz = xf[2] * scale;
+  // cv::Affine3d * cv::Point3f -> Point3d -> Point3f
+  float zr = (float)(s_T[0][8] * (double)px + s_T[0][9] * (double)py + s_T[0][10] * (double)pz + s_T[0][11]);
+  float zc = (float)(s_T[1][8] * (double)px + s_T[1][9] * (double)py + s_T[1][10] * (double)pz + s_T[1][11]);
+  A.X3[3 * (b + i)] = px; A.X3[3 * (b + i) + 1] = py; A.X3[3 * (b + i) + 2] = pz;
+  A.valid[b + i] = (pose_ok && zr > 0 && zc > 0) ? 1 : 0;
+}
+
+int geom_triangulate_matches(mvo_ctx* ctx, int nslots, int max_matches, const mvo_match* matches, const int* n_matches,
+                             const float* kf_xy, const float* cur_xy, const double* kf_pose, const double* cur_pose,
+                             const int* pnp_result, const double K[9], float* X3, u8* valid) {
+  if (max_matches <= 0) return MVO_OK;
+  TriBatchArgs A;
+  A.matches = matches; A.n_matches = n_matches; A.kf_xy = kf_xy; A.cur_xy = cur_xy; A.kf_pose = kf_pose; A.cur_pose = cur_pose;
+  A.pnp_result = pnp_result; A.cam = CamK{K[0], K[4], K[2], K[5]}; A.cap = ctx->maxpts; A.X3 = X3; A.valid = valid;
+  dim3 grid((max_matches + 255) / 256, nslots);
+  hipLaunchKernelGGL(triangulate_matches_kernel, grid, dim3(256), 0, ctx->stream, A);
+  return MVO_OK;
+}
 
 static int upload_pairs(mvo_ctx* ctx, const float* p1, int c1, const float* p2, int c2, int n) {
   GeomState* g = ctx->geom;

@@ -141,6 +141,27 @@ struct MatchState {
 };
 
 
+struct GeomState {
+  float* d_m1 = nullptr;   // [B][maxpts][3]
+  float* d_m2 = nullptr;   // [B][maxpts][2]
+  int* d_n = nullptr;      // [B]
+  u8* d_mask = nullptr;    // [B][maxpts]
+  double* d_model = nullptr;  // [B][16]
+  int* d_result = nullptr;    // [B][8]
+  // PnP refine
+  int* d_inl = nullptr;       // [B][maxpts] inlier indices
+  double* d_pose = nullptr;   // [B][8] rvec, tvec
+  float* d_x3 = nullptr;      // [B][maxpts][3]
+  // second set for running H and F side by side in the pipeline
+  u8* d_mask2 = nullptr;
+  double* d_model2 = nullptr;
+  int* d_result2 = nullptr;
+  double* d_tmp = nullptr;    // 64 doubles of scratch
+  double* h_model = nullptr;  // pinned
+  int* h_result = nullptr;
+};
+
+
 // Level geometry helpers (host).
 struct LkLevels {
   int n;  // number of levels actually used (maxLevel+1 after the <= winSize early stop)
@@ -163,7 +184,15 @@ int lk_build_pyramid(mvo_ctx* ctx, int set, const LkLevels& L, int nslots);
 int lk_track_device(mvo_ctx* ctx, int prev_set, int cur_set, const LkLevels& L, int nslots, int max_n);
 int orb_run(mvo_ctx* ctx, int w, int h, int nslots, bool describe, std::vector<int>& kp_base);
 int match_device(mvo_ctx* ctx, int nslots, int max_nq, double ratio);
-int pipe_geometry_stages(mvo_ctx* ctx, unsigned stages, mvo_step_result* out);
+int geom_ransac_h(mvo_ctx* ctx, int nslots, const float* p1, const float* p2, const int* d_n, double thr, int max_iters, double conf,
+                  u8* mask, double* model, int* result);
+int geom_ransac_f(mvo_ctx* ctx, int nslots, const float* p1, const float* p2, const int* d_n, double thr, int max_iters, double conf,
+                  u8* mask, double* model, int* result);
+int geom_pnp(mvo_ctx* ctx, int nslots, const float* obj, const float* img, const int* d_n, const double K[9], int iters, float reproj,
+             double conf, u8* mask, double* model, int* result, int* inl, double* pose);
+int geom_triangulate_matches(mvo_ctx* ctx, int nslots, int max_matches, const mvo_match* matches, const int* n_matches,
+                             const float* kf_xy, const float* cur_xy, const double* kf_pose, const double* cur_pose,
+                             const int* pnp_result, const double K[9], float* X3, u8* valid);
 
 // Upload a host image (mono8 or BGR8, arbitrary stride) into a device mono8 ImgSet slot (async on ctx->stream).
 int upload_gray(mvo_ctx* ctx, const uint8_t* img, int w, int h, int stride, int channels, u8* d_dst,

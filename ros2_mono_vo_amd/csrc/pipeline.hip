@@ -106,6 +106,16 @@ struct PipeState {
   double K[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   double dist[5] = {0, 0, 0, 0, 0};
   bool seeded = false;
+  // landmark hand-over (device-resident Frame/KeyFrame bookkeeping, src/tracker.cpp:193-234)
+  u8* d_kf_has = nullptr;     // [B][maxpts] key-frame observation has a landmark
+  float* d_kf_lm = nullptr;   // [B][maxpts][3]
+  u8* d_cur_has = nullptr;
+  float* d_cur_lmk = nullptr; // [B][maxpts][3]
+  int* d_winner = nullptr;    // [B][maxpts] last valid match per current key-point
+  float* d_tri = nullptr;     // [B][maxpts][3] triangulated matches
+  u8* d_tri_ok = nullptr;     // [B][maxpts]
+  double* d_kf_pose = nullptr;  // [B][8] T_cw of the last key-frame (rvec, tvec)
+  int* d_ntri = nullptr;      // [B]
   int trk_max_n = 0;  // host-side bound on the per-slot track count (grid sizing)
   int kf_max_n = 0;   // host-side bound on the key-frame descriptor count
 };
@@ -128,7 +138,19 @@ int pipe_state_create(mvo_ctx* ctx) {
   MVO_HIP(hipMalloc(&p->d_ncur, ctx->B * sizeof(int)));
   MVO_HIP(hipMalloc(&p->d_kp_xy, np * 2 * sizeof(float)));
   MVO_HIP(hipMalloc(&p->d_kfkp_xy, np * 2 * sizeof(float)));
-  MVO_HIP(hipHostMalloc(&p->h_ints, (size_t)ctx->B * 16 * sizeof(int), hipHostMallocDefault));
+  MVO_HIP(hipMalloc(&p->d_kf_has, np));
+  MVO_HIP(hipMalloc(&p->d_kf_lm, np * 3 * sizeof(float)));
+  MVO_HIP(hipMalloc(&p->d_cur_has, np));
+  MVO_HIP(hipMalloc(&p->d_cur_lmk, np * 3 * sizeof(float)));
+  MVO_HIP(hipMalloc(&p->d_winner, np * sizeof(int)));
+  MVO_HIP(hipMalloc(&p->d_tri, np * 3 * sizeof(float)));
+  MVO_HIP(hipMalloc(&p->d_tri_ok, np));
+  MVO_HIP(hipMalloc(&p->d_kf_pose, (size_t)ctx->B * 8 * sizeof(double)));
+  MVO_HIP(hipMalloc(&p->d_ntri, ctx->B * sizeof(int)));
+  MVO_HIP(hipMemsetAsync(p->d_kf_has, 0, np, ctx->stream));
+  MVO_HIP(hipMemsetAsync(p->d_kf_lm, 0, np * 3 * sizeof(float), ctx->stream));
+  MVO_HIP(hipMemsetAsync(p->d_kf_pose, 0, (size_t)ctx->B * 8 * sizeof(double), ctx->stream));
+  MVO_HIP(hipHostMalloc(&p->h_ints, (size_t)ctx->B * 64 * sizeof(int), hipHostMallocDefault));
   MVO_HIP(hipMemsetAsync(p->d_lm, 0, np * 3 * sizeof(float), ctx->stream));
   MVO_HIP(hipMemsetAsync(p->d_kf_pts, 0, np * 2 * sizeof(float), ctx->stream));
   return MVO_OK;
@@ -137,7 +159,8 @@ int pipe_state_create(mvo_ctx* ctx) {
 void pipe_state_destroy(mvo_ctx* ctx) {
   PipeState* p = ctx->pipe;
   if (p) {
-    void* dev[] = {p->d_ring, p->d_lm, p->d_kf_pts, p->d_cur_pts, p->d_cur_lm, p->d_cur_kf, p->d_ncur, p->d_kp_xy, p->d_kfkp_xy};
+    void* dev[] = {p->d_ring, p->d_lm, p->d_kf_pts, p->d_cur_pts, p->d_cur_lm, p->d_cur_kf, p->d_ncur, p->d_kp_xy, p->d_kfkp_xy,
+                   p->d_kf_has, p->d_kf_lm, p->d_cur_has, p->d_cur_lmk, p->d_winner, p->d_tri, p->d_tri_ok, p->d_kf_pose, p->d_ntri};
     for (void* q : dev) (void)hipFree(q);
     if (p->h_ints) (void)hipHostFree(p->h_ints);
     delete p;
@@ -228,6 +251,82 @@ __global__ __launch_bounds__(256) void scatter_kp_kernel(const mvo_keypoint* __r
   }
 }
 
+
+// ---- landmark hand-over of Tracker::add_new_keyframe (src/tracker.cpp:211-227) --------------------------
+// Sequential reference semantics: matches are visited in order, so when several matches share a train
+// index the LAST valid one decides that key-point's landmark.  Phase 1: winner[t] = max valid match index.
+__global__ __launch_bounds__(256) void landmark_winner_kernel(const mvo_match* __restrict__ matches, const int* __restrict__ n_matches,
+                                                              const u8* __restrict__ valid, int cap, int* __restrict__ winner) {
+  const int slot = blockIdx.y;
+  const int n = min(max(n_matches[slot], 0), cap);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const size_t b = (size_t)slot * cap;
+  if (valid[b + i]) atomicMax(&winner[b + matches[b + i].train_idx], i);
+}
+
+// Phase 2 (one block per slot): per current key-point take the winning match: reuse the key-frame
+// observation's landmark if it has one, else the freshly triangulated point; then an ordered compaction
+// of the key-points WITH landmarks becomes the next frame's tracks (Frame::get_points_2d(WITH_LANDMARKS)).
+__global__ __launch_bounds__(1024) void landmark_assign_kernel(const mvo_match* __restrict__ matches, const int* __restrict__ winner,
+                                                               const int* __restrict__ n_kp, const float* __restrict__ kp_xy,
+                                                               const u8* __restrict__ kf_has, const float* __restrict__ kf_lm,
+                                                               const float* __restrict__ tri, const u8* __restrict__ tri_ok,
+                                                               const int* __restrict__ n_matches, int cap,
+                                                               u8* __restrict__ cur_has, float* __restrict__ cur_lm,
+                                                               float* __restrict__ trk_xy, float* __restrict__ trk_lm,
+                                                               float* __restrict__ trk_kf, int* __restrict__ n_trk, int* __restrict__ n_tri) {
+  __shared__ int s_wave[16];
+  __shared__ int s_base;
+  __shared__ int s_tri;
+  const int slot = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = min(max(n_kp[slot], 0), cap);
+  const size_t b = (size_t)slot * cap;
+  if (threadIdx.x == 0) { s_base = 0; s_tri = 0; }
+  __syncthreads();
+  int tri_cnt = 0;
+  const int nm = min(max(n_matches[slot], 0), cap);
+  for (int i = threadIdx.x; i < nm; i += 1024) tri_cnt += tri_ok[b + i] ? 1 : 0;
+  atomicAdd(&s_tri, tri_cnt);
+  for (int t0 = 0; t0 < n; t0 += 1024) {
+    int t = t0 + threadIdx.x;
+    bool has = false;
+    float lx = 0, ly = 0, lz = 0;
+    if (t < n) {
+      int wi = winner[b + t];
+      if (wi >= 0) {
+        int q = matches[b + wi].query_idx;
+        has = true;
+        if (kf_has[b + q]) { lx = kf_lm[3 * (b + q)]; ly = kf_lm[3 * (b + q) + 1]; lz = kf_lm[3 * (b + q) + 2]; }
+        else { lx = tri[3 * (b + wi)]; ly = tri[3 * (b + wi) + 1]; lz = tri[3 * (b + wi) + 2]; }
+      }
+      cur_has[b + t] = has ? 1 : 0;
+      cur_lm[3 * (b + t)] = lx; cur_lm[3 * (b + t) + 1] = ly; cur_lm[3 * (b + t) + 2] = lz;
+    }
+    unsigned long long m = __ballot(has);
+    int pre = __popcll(m & ((1ull << lane) - 1));
+    if (lane == 0) s_wave[wave] = __popcll(m);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wave; w++) off += s_wave[w];
+    if (has) {
+      size_t o = b + off + pre;
+      float x = kp_xy[2 * (b + t)], y = kp_xy[2 * (b + t) + 1];
+      trk_xy[2 * o] = x; trk_xy[2 * o + 1] = y;
+      trk_kf[2 * o] = x; trk_kf[2 * o + 1] = y;
+      trk_lm[3 * o] = lx; trk_lm[3 * o + 1] = ly; trk_lm[3 * o + 2] = lz;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int tt = 0;
+      for (int w = 0; w < 16; w++) tt += s_wave[w];
+      s_base += tt;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { n_trk[slot] = s_base; n_tri[slot] = s_tri; }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // API
 // ---------------------------------------------------------------------------------------------------
@@ -267,7 +366,7 @@ static int pipe_publish_orb(mvo_ctx* ctx, const std::vector<int>& kp_base, int* 
   OrbState* o = ctx->orb;
   MatchState* m = ctx->match;
   int B = ctx->B;
-  int* hb = p->h_ints;
+  int* hb = p->h_ints + 16 * B;  // staging region of its own (the step's counters live in [0, 5B))
   int mx = 0;
   for (int s = 0; s <= B; s++) hb[s] = kp_base[s];
   for (int s = 0; s < B; s++) {
@@ -284,18 +383,26 @@ static int pipe_publish_orb(mvo_ctx* ctx, const std::vector<int>& kp_base, int* 
   return MVO_OK;
 }
 
-// key-frame := current frame (descriptors, key-point positions); tracks := all current key-points.
-static int pipe_promote_keyframe(mvo_ctx* ctx, int max_n) {
+// key-frame := current frame: descriptors, key-point positions and per-observation landmarks change sides.
+// `all_tracks`: seed mode — every key-point becomes a track (landmarks supplied by mvo_batch_set_landmarks).
+static int pipe_promote_keyframe(mvo_ctx* ctx, int max_n, bool all_tracks) {
   PipeState* p = ctx->pipe;
   MatchState* m = ctx->match;
   std::swap(m->d_q, m->d_t);
   std::swap(m->d_nq, m->d_nt);
   std::swap(p->d_kfkp_xy, p->d_kp_xy);
-  p->kf_max_n = p->trk_max_n = max_n;
+  p->kf_max_n = max_n;
   size_t np = (size_t)ctx->B * ctx->maxpts;
-  MVO_HIP(hipMemcpyAsync(ctx->d_prev_pts, p->d_kfkp_xy, np * 2 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
-  MVO_HIP(hipMemcpyAsync(p->d_kf_pts, p->d_kfkp_xy, np * 2 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
-  MVO_HIP(hipMemcpyAsync(ctx->d_npts, m->d_nq, (size_t)ctx->B * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+  if (all_tracks) {
+    p->trk_max_n = max_n;
+    MVO_HIP(hipMemcpyAsync(ctx->d_prev_pts, p->d_kfkp_xy, np * 2 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    MVO_HIP(hipMemcpyAsync(p->d_kf_pts, p->d_kfkp_xy, np * 2 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    MVO_HIP(hipMemcpyAsync(ctx->d_npts, m->d_nq, (size_t)ctx->B * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+    MVO_HIP(hipMemsetAsync(p->d_kf_has, 0, np, ctx->stream));
+  } else {
+    std::swap(p->d_kf_has, p->d_cur_has);
+    std::swap(p->d_kf_lm, p->d_cur_lmk);
+  }
   return MVO_OK;
 }
 
@@ -312,7 +419,8 @@ extern "C" int mvo_batch_seed(mvo_ctx* ctx, int frame_idx, int* n_keypoints) {
   if ((rc = orb_run(ctx, p->w, p->h, ctx->B, true, base))) return rc;
   int mx = 0;
   if ((rc = pipe_publish_orb(ctx, base, &mx))) return rc;
-  if ((rc = pipe_promote_keyframe(ctx, mx))) return rc;
+  if ((rc = pipe_promote_keyframe(ctx, mx, true))) return rc;
+  MVO_HIP(hipMemsetAsync(p->d_kf_pose, 0, (size_t)ctx->B * 8 * sizeof(double), ctx->stream));  // T_cw = identity
   MVO_HIP(hipStreamSynchronize(ctx->stream));
   if (n_keypoints)
     for (int s = 0; s < ctx->B; s++) n_keypoints[s] = base[s + 1] - base[s];
@@ -336,10 +444,15 @@ extern "C" int mvo_batch_get_tracks(mvo_ctx* ctx, int slot, float* pts, int cap,
   return MVO_OK;
 }
 
+// Landmarks of the current tracks of `slot`, in track order.  After mvo_batch_seed the tracks are all
+// key-points of the key-frame, so the same positions also become the key-frame observations' landmarks.
 extern "C" int mvo_batch_set_landmarks(mvo_ctx* ctx, int slot, const float* xyz, int n) {
   if (!ctx || !ctx->pipe || !xyz || slot < 0 || slot >= ctx->B || n < 0 || n > ctx->maxpts) return MVO_E_ARG;
-  MVO_HIP(hipMemcpyAsync(ctx->pipe->d_lm + (size_t)slot * ctx->maxpts * 3, xyz, (size_t)n * 3 * sizeof(float),
-                         hipMemcpyHostToDevice, ctx->stream));
+  PipeState* p = ctx->pipe;
+  size_t o = (size_t)slot * ctx->maxpts;
+  MVO_HIP(hipMemcpyAsync(p->d_lm + o * 3, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  MVO_HIP(hipMemcpyAsync(p->d_kf_lm + o * 3, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  MVO_HIP(hipMemsetAsync(p->d_kf_has + o, 1, (size_t)n, ctx->stream));
   MVO_HIP(hipStreamSynchronize(ctx->stream));
   return MVO_OK;
 }
@@ -348,15 +461,21 @@ extern "C" int mvo_batch_step(mvo_ctx* ctx, int frame_idx, unsigned stages, mvo_
   if (!ctx || !ctx->pipe || !out) return MVO_E_ARG;
   PipeState* p = ctx->pipe;
   MatchState* m = ctx->match;
+  GeomState* g = ctx->geom;
   if (!p->seeded || frame_idx < 0 || frame_idx >= p->ring) { ctx->set_error("mvo_batch_step: not seeded / bad frame"); return MVO_E_ARG; }
   const int B = ctx->B;
+  const size_t np = (size_t)B * ctx->maxpts;
   int rc;
   LkLevels L = lk_levels(p->w, p->h, ctx->cfg.lk_win, ctx->cfg.lk_max_level);
   const int prev_set = ctx->lk_cur, cur_set = ctx->lk_cur ^ 1;
   memset(out, 0, sizeof(mvo_step_result) * B);
   if ((rc = pipe_load_frame(ctx, frame_idx, cur_set))) return rc;
   { ProfScope ps(ctx, "lk_pyramid"); lk_build_pyramid(ctx, cur_set, L, B); }
-  int* hb = p->h_ints + 4 * B;  // [0,B): n_prev, [B,2B): n_tracked, [2B,3B): n_matches
+  // pinned layout: hb[0..B) n_prev, [B..2B) n_tracked, [2B..3B) n_matches, [3B..4B) n_tri, [4B..5B) n_new_tracks,
+  //                hr[0..8B) pnp result, [8B..16B) H result, [16B..24B) F result; hp: [B][8] pose
+  int* hb = p->h_ints;
+  int* hr = g->h_result;
+  double* hp = g->h_model;
   if (stages & MVO_STAGE_LK) {
     { ProfScope ps(ctx, "lk_track"); lk_track_device(ctx, prev_set, cur_set, L, B, p->trk_max_n); }
     ProfScope ps(ctx, "lk_filter");
@@ -366,38 +485,81 @@ extern "C" int mvo_batch_step(mvo_ctx* ctx, int frame_idx, unsigned stages, mvo_
     MVO_HIP(hipMemcpyAsync(hb, ctx->d_npts, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     MVO_HIP(hipMemcpyAsync(hb + B, p->d_ncur, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   }
-  int rc2 = pipe_geometry_stages(ctx, stages, out);
-  if (rc2) return rc2;
+  const bool do_pnp = (stages & MVO_STAGE_LK) && (stages & MVO_STAGE_PNP);
+  const bool do_hf = (stages & MVO_STAGE_LK) && (stages & MVO_STAGE_HF);
+  if (do_pnp) {
+    ProfScope ps(ctx, "pnp");
+    geom_pnp(ctx, B, p->d_cur_lm, p->d_cur_pts, p->d_ncur, p->K, 100, 8.0f, 0.99, g->d_mask, g->d_model, g->d_result, g->d_inl, g->d_pose);
+    MVO_HIP(hipMemcpyAsync(hr, g->d_result, (size_t)B * 8 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MVO_HIP(hipMemcpyAsync(hp, g->d_pose, (size_t)B * 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (do_hf) {
+    // Tracker::has_parallax: key-frame positions of the tracked landmarks vs their current positions
+    { ProfScope ps(ctx, "ransac_h");
+      geom_ransac_h(ctx, B, p->d_cur_kf, p->d_cur_pts, p->d_ncur, ctx->cfg.ransac_reproj_thresh, 2000, 0.995, g->d_mask2, g->d_model2, g->d_result2); }
+    MVO_HIP(hipMemcpyAsync(hr + 8 * B, g->d_result2, (size_t)B * 8 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    { ProfScope ps(ctx, "ransac_f");
+      geom_ransac_f(ctx, B, p->d_cur_kf, p->d_cur_pts, p->d_ncur, ctx->cfg.ransac_reproj_thresh, 1000, 0.99, g->d_mask2, g->d_model2, g->d_result2); }
+    MVO_HIP(hipMemcpyAsync(hr + 16 * B, g->d_result2, (size_t)B * 8 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  }
   std::vector<int> base;
   if (stages & MVO_STAGE_ORB) {
     if ((rc = orb_run(ctx, p->w, p->h, B, true, base))) return rc;
     int mx = 0;
     if ((rc = pipe_publish_orb(ctx, base, &mx))) return rc;
-    if (stages & MVO_STAGE_MATCH) {
+    const bool do_match = stages & MVO_STAGE_MATCH;
+    const bool do_tri = do_match && do_pnp && (stages & MVO_STAGE_TRIANG);
+    if (do_match) {
       ProfScope ps(ctx, "match");
       match_device(ctx, B, p->kf_max_n, ctx->cfg.lowes_distance_ratio);
       MVO_HIP(hipMemcpyAsync(hb + 2 * B, m->d_nout, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     }
-    if ((rc = pipe_promote_keyframe(ctx, mx))) return rc;
+    if (do_tri) {
+      ProfScope ps(ctx, "triangulate");
+      int max_m = p->kf_max_n;  // matches <= queries
+      geom_triangulate_matches(ctx, B, max_m, m->d_out, m->d_nout, p->d_kfkp_xy, p->d_kp_xy, p->d_kf_pose, g->d_pose, g->d_result, p->K,
+                               p->d_tri, p->d_tri_ok);
+      MVO_HIP(hipMemsetAsync(p->d_winner, 0xFF, np * sizeof(int), ctx->stream));
+      dim3 grid((max_m + 255) / 256, B);
+      hipLaunchKernelGGL(landmark_winner_kernel, grid, dim3(256), 0, ctx->stream, m->d_out, m->d_nout, p->d_tri_ok, ctx->maxpts, p->d_winner);
+      hipLaunchKernelGGL(landmark_assign_kernel, dim3(B), dim3(1024), 0, ctx->stream, m->d_out, p->d_winner, m->d_nt, p->d_kp_xy,
+                         p->d_kf_has, p->d_kf_lm, p->d_tri, p->d_tri_ok, m->d_nout, ctx->maxpts, p->d_cur_has, p->d_cur_lmk,
+                         ctx->d_prev_pts, p->d_lm, p->d_kf_pts, ctx->d_npts, p->d_ntri);
+      MVO_HIP(hipMemcpyAsync(hb + 3 * B, p->d_ntri, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      MVO_HIP(hipMemcpyAsync(hb + 4 * B, ctx->d_npts, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      MVO_HIP(hipMemcpyAsync(p->d_kf_pose, g->d_pose, (size_t)B * 8 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+      if ((rc = pipe_promote_keyframe(ctx, mx, false))) return rc;
+    } else {
+      // no triangulation stage: every key-point of the new key-frame becomes a track (landmarks keep their last values)
+      if ((rc = pipe_promote_keyframe(ctx, mx, true))) return rc;
+    }
   } else if (stages & MVO_STAGE_LK) {
     // no key-frame: survivors become the next frame's tracks (src/tracker.cpp:331)
-    size_t np = (size_t)B * ctx->maxpts;
     MVO_HIP(hipMemcpyAsync(ctx->d_prev_pts, p->d_cur_pts, np * 2 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     MVO_HIP(hipMemcpyAsync(p->d_lm, p->d_cur_lm, np * 3 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     MVO_HIP(hipMemcpyAsync(p->d_kf_pts, p->d_cur_kf, np * 2 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     MVO_HIP(hipMemcpyAsync(ctx->d_npts, p->d_ncur, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
   }
   MVO_HIP(hipStreamSynchronize(ctx->stream));
-  if ((stages & MVO_STAGE_LK) && !(stages & MVO_STAGE_ORB)) {
-    int mx = 0;
-    for (int s = 0; s < B; s++) mx = hb[B + s] > mx ? hb[B + s] : mx;
-    p->trk_max_n = mx;
-  }
+  const bool tri_done = (stages & MVO_STAGE_ORB) && (stages & MVO_STAGE_MATCH) && do_pnp && (stages & MVO_STAGE_TRIANG);
+  int mx_trk = 0;
   for (int s = 0; s < B; s++) {
     if (stages & MVO_STAGE_LK) { out[s].n_prev = hb[s]; out[s].n_tracked = hb[B + s]; }
+    if (do_pnp) {
+      out[s].pnp_ok = hr[8 * s] && hr[8 * s + 6];
+      out[s].n_pnp_inliers = hr[8 * s + 5];
+      for (int k = 0; k < 3; k++) { out[s].rvec[k] = hp[8 * s + k]; out[s].tvec[k] = hp[8 * s + 3 + k]; }
+    }
+    if (do_hf) {
+      out[s].score_h = hr[8 * B + 8 * s] ? hr[8 * B + 8 * s + 1] : 0;
+      out[s].score_f = hr[16 * B + 8 * s] ? hr[16 * B + 8 * s + 1] : 0;
+    }
     if (stages & MVO_STAGE_ORB) out[s].n_keypoints = base[s + 1] - base[s];
     if ((stages & MVO_STAGE_ORB) && (stages & MVO_STAGE_MATCH)) out[s].n_matches = hb[2 * B + s];
+    if (tri_done) { out[s].n_triangulated = hb[3 * B + s]; mx_trk = hb[4 * B + s] > mx_trk ? hb[4 * B + s] : mx_trk; }
+    else if (!(stages & MVO_STAGE_ORB)) mx_trk = hb[B + s] > mx_trk ? hb[B + s] : mx_trk;
   }
+  if (tri_done || ((stages & MVO_STAGE_LK) && !(stages & MVO_STAGE_ORB))) p->trk_max_n = mx_trk;
   ctx->lk_cur = cur_set;
   return MVO_OK;
 }
