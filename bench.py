@@ -84,17 +84,13 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from ros2_mono_vo_amd import Context, _lib, synth
+    from ros2_mono_vo_amd import parallel
 
     W, H, B, K, Wm = args.width, args.height, args.batch, args.steps, args.warmup
     n_frames = K + Wm + 1
     # intrinsics: rank 0 owns them, one RCCL broadcast over xGMI (the path's only collective)
-    Kd = torch.zeros(14, dtype=torch.float64, device="cuda")
-    if rank == 0:
-        Kd[:9] = torch.from_numpy(synth.default_K(W, H).reshape(9))
-    if dist is not None:
-        dist.broadcast(Kd, src=0)
-    Kmat = Kd[:9].cpu().numpy().reshape(3, 3)
-    dcoef = Kd[9:].cpu().numpy()
+    Kmat, dcoef = parallel.broadcast_intrinsics(synth.default_K(W, H) if rank == 0 else np.zeros((3, 3)), np.zeros(5), dist,
+                                                device="cuda")
 
     streams = make_streams(W, H, n_frames, min(args.distinct, B), 0x5EED0003 + 64 * rank)
     ctx = Context(max_width=W, max_height=H, batch=B, nfeatures=args.nfeatures, max_points=4096,
@@ -133,10 +129,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     ctx.profile_enable(False)
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = parallel.max_over_ranks(dt, dist, device="cuda")
 
     prof = {}
     for name in ("frame_fanout", "lk_pyramid", "lk_track", "lk_filter", "orb_detect", "orb_describe", "match", "pnp",

@@ -1,0 +1,252 @@
+"""First-principles known-answer and planted-ground-truth tests that pin the CPU oracle (no GPU needed).
+The reference ships no tests or golden vectors and OpenCV is unavailable offline ("parity unpinned"), so these
+are what stands behind the oracle: hand-computable cases, closed-form maths and synthetic geometry with known
+answers."""
+import numpy as np
+import pytest
+
+import oracle_py as O
+from ros2_mono_vo_amd import synth
+
+
+# ---- cv::RNG ---------------------------------------------------------------------------------------
+def test_rng_mwc_recurrence():
+    state = 0xFFFFFFFFFFFFFFFF
+    exp = []
+    for _ in range(6):
+        state = ((state & 0xFFFFFFFF) * 4164903690 + (state >> 32)) & 0xFFFFFFFFFFFFFFFF
+        exp.append(state & 0xFFFFFFFF)
+    assert O.rng_sequence(0xFFFFFFFFFFFFFFFF, 6) == exp
+
+
+def test_ransac_update_num_iters_formula():
+    # log(1-p)/log(1-(1-ep)^m), round half to even, clamped by maxIters
+    assert O.ransac_update_num_iters(0.99, 0.5, 4, 2000) == round(np.log(0.01) / np.log(1 - 0.5 ** 4))
+    assert O.ransac_update_num_iters(0.995, 0.2, 4, 2000) == round(np.log(0.005) / np.log(1 - 0.8 ** 4))
+    assert O.ransac_update_num_iters(0.99, 0.9, 7, 1000) == 1000      # clamp
+    assert O.ransac_update_num_iters(0.99, 0.0, 5, 100) == 0          # denom < DBL_MIN
+
+
+# ---- image primitives ---------------------------------------------------------------------------------
+def test_pyrdown_by_hand():
+    img = np.arange(9 * 7, dtype=np.uint8).reshape(7, 9) * 3
+    k = np.array([1, 4, 6, 4, 1])
+
+    def refl(p, n):
+        return -p if p < 0 else (2 * (n - 1) - p if p >= n else p)
+    out = np.zeros((4, 5), np.uint8)
+    for y in range(4):
+        for x in range(5):
+            acc = 0
+            for dy in range(5):
+                for dx in range(5):
+                    acc += int(k[dy]) * int(k[dx]) * int(img[refl(2 * y - 2 + dy, 7), refl(2 * x - 2 + dx, 9)])
+            out[y, x] = (acc + 128) >> 8
+    assert np.array_equal(O.pyrdown(img), out)
+
+
+def test_resize_exact_identity_and_constant():
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (37, 53), dtype=np.uint8)
+    assert np.array_equal(O.resize_linear_exact(img, 53, 37), img)
+    c = np.full((40, 60), 77, np.uint8)
+    assert np.array_equal(O.resize_linear_exact(c, 50, 33), np.full((33, 50), 77, np.uint8))
+    # 2:1 downscale samples exactly between pixel pairs -> rounded mean of the 2x2 block
+    e = rng.integers(0, 256, (20, 30), dtype=np.uint8)
+    r = O.resize_linear_exact(e, 15, 10)
+    blk = e.reshape(10, 2, 15, 2).astype(np.int32)
+    exp = ((blk[:, 0, :, 0] + blk[:, 0, :, 1]) * 128 * 128 + (blk[:, 1, :, 0] + blk[:, 1, :, 1]) * 128 * 128 + 32768) >> 16
+    assert np.array_equal(r, exp.astype(np.uint8))
+
+
+def test_gauss7_taps():
+    c = np.full((32, 32), 100, np.uint8)
+    # blur_mode 0: taps sum to 257/256 per axis -> (100*257*257 + 32768) >> 16
+    assert np.all(O.gauss7(c, 0) == (100 * 257 * 257 + 32768) >> 16)
+    assert np.all(O.gauss7(c, 1) == 100)          # bit-exact ED taps sum to 256
+    imp = np.zeros((15, 15), np.uint8)
+    imp[7, 7] = 255
+    k = np.array([18, 34, 49, 55, 49, 34, 18])
+    exp = (np.outer(k, k) * 255 + 32768) >> 16
+    assert np.array_equal(O.gauss7(imp, 0)[4:11, 4:11], exp.astype(np.uint8))
+
+
+def test_fast_atan2_polynomial():
+    for ang in np.linspace(0, 359.5, 73):
+        y, x = np.sin(np.deg2rad(ang)) * 37.0, np.cos(np.deg2rad(ang)) * 37.0
+        d = abs(O.fast_atan2(y, x) - ang)
+        assert min(d, 360 - d) < 0.3
+    assert O.fast_atan2(0.0, 1.0) == 0.0 and abs(O.fast_atan2(1.0, 0.0) - 90.0) < 1e-4
+
+
+# ---- FAST ---------------------------------------------------------------------------------------------
+def _fast_patch(center, ring, bg=128):
+    img = np.full((15, 15), bg, np.uint8)
+    circ = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0),
+            (-3, 1), (-2, 2), (-1, 3)]
+    img[7, 7] = center
+    for (dx, dy), v in zip(circ, ring):
+        img[7 + dy, 7 + dx] = v
+    return img
+
+
+def test_fast_known_patches():
+    # 9 contiguous brighter pixels: corner; score = max threshold keeping it a corner
+    ring = [200] * 9 + [100] * 7
+    k = O.fast9_nms(_fast_patch(100, ring), 20)
+    assert [tuple(r) for r in k if (r[0], r[1]) == (7, 7)] == [(7, 7, 99)]       # min(|d|) - 1 = 100 - 1
+    ring = [200] * 8 + [100] * 8                                                     # only 8 contiguous: not a corner
+    assert not any((r[0], r[1]) == (7, 7) for r in O.fast9_nms(_fast_patch(100, ring), 20))
+    ring = [60] * 5 + [100] * 7 + [60] * 4                                           # dark arc wrapping around index 0
+    k = O.fast9_nms(_fast_patch(100, ring), 20)
+    assert any((r[0], r[1], r[2]) == (7, 7, 39) for r in k)
+    ring = [121] * 16                                                               # |d| = 21 > t=20 everywhere
+    assert any((r[0], r[1], r[2]) == (7, 7, 20) for r in O.fast9_nms(_fast_patch(100, ring), 20))
+    ring = [120] * 16                                                               # |d| = 20 is not > 20
+    assert not any((r[0], r[1]) == (7, 7) for r in O.fast9_nms(_fast_patch(100, ring), 20))
+
+
+def test_fast_nms_is_strict_and_row_major():
+    fr = synth.gen_stream(160, 120, 42, 1)[0]
+    k = O.fast9_nms(fr, 20)
+    assert len(k) > 20
+    order = k[:, 1] * 1000 + k[:, 0]
+    assert np.all(np.diff(order) > 0)                       # row-major, no duplicates
+    assert k[:, 0].min() >= 3 and k[:, 0].max() <= 160 - 4 and k[:, 1].min() >= 3 and k[:, 1].max() <= 120 - 4
+    s = {(x, y): sc for x, y, sc in k}
+    for (x, y), sc in s.items():                            # strict maxima among accepted corners
+        for dx in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                if (dx or dy) and (x + dx, y + dy) in s:
+                    assert False, "two adjacent survivors"
+
+
+# ---- ORB ----------------------------------------------------------------------------------------------
+def test_orb_level_geometry_and_quotas():
+    lw, lh, sc, q = O.orb_level_info(1280, 720, 2000)
+    assert list(lw) == [1280, 1067, 889, 741, 617, 514, 429, 357] and list(lh) == [720, 600, 500, 417, 347, 289, 241, 201]
+    assert list(q) == [434, 362, 302, 251, 209, 175, 145, 122] and q.sum() == 2000
+    lw, lh, sc, q = O.orb_level_info(640, 480, 1000)
+    assert list(lw) == [640, 533, 444, 370, 309, 257, 214, 179] and list(q) == [217, 181, 151, 126, 105, 87, 73, 60]
+
+
+def test_orb_output_invariants():
+    fr = synth.gen_stream(640, 480, 0x5EED0002, 1)[0]
+    k, d = O.orb_detect_and_compute(fr, 1000)
+    assert len(k) >= 1000 and d.shape == (len(k), 32)
+    assert np.array_equal(np.bincount(k["octave"], minlength=8)[:8] >= [217, 181, 151, 126, 105, 87, 73, 60], [True] * 8)
+    assert np.all((k["angle"] >= 0) & (k["angle"] < 360)) and np.all(k["class_id"] == -1)
+    lw, lh, sc, _ = O.orb_level_info(640, 480, 1000)
+    assert np.allclose(k["size"], 31 * sc[k["octave"]])
+    x, y = k["x"] / sc[k["octave"]], k["y"] / sc[k["octave"]]          # edgeThreshold 31 in level coordinates
+    assert np.all(x >= 31 - 1e-3) and np.all(x < lw[k["octave"]] - 31 + 1e-3)
+    assert np.all(y >= 31 - 1e-3) and np.all(y < lh[k["octave"]] - 31 + 1e-3)
+    # a flat image has no corners; tiny images yield nothing instead of failing
+    assert len(O.orb_detect_and_compute(np.full((200, 200), 90, np.uint8), 500)[0]) == 0
+    assert len(O.orb_detect_and_compute(fr[:40, :40], 500)[0]) == 0
+
+
+# ---- matcher ----------------------------------------------------------------------------------------------
+def test_matcher_vs_numpy_popcount_and_ties():
+    rng = np.random.default_rng(1)
+    q = rng.integers(0, 256, (50, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (80, 32), dtype=np.uint8)
+    t[10] = t[3]                                                     # exact tie: lower train index first
+    q[7] = t[3]
+    D = np.unpackbits(q[:, None, :] ^ t[None, :, :], axis=2).sum(2)
+    m = O.match_knn2_ratio(q, t, 2.0)                                # ratio 2: every query with 2 neighbours passes unless d0==d1==0
+    for r in m:
+        order = np.lexsort((np.arange(80), D[r["query_idx"]]))
+        assert r["train_idx"] == order[0] and r["distance"] == D[r["query_idx"], order[0]]
+    assert 7 not in m["query_idx"]                                   # d0 = d1 = 0: 0 < 2*0 is false
+    strict = O.match_knn2_ratio(q, t, 0.7)
+    for r in strict:
+        d = np.sort(D[r["query_idx"]])
+        assert d[0] < 0.7 * d[1]
+
+
+# ---- LK ---------------------------------------------------------------------------------------------------
+def test_lk_zero_motion_and_translation():
+    fr = synth.gen_stream(320, 240, 7, 1)[0]
+    k, _ = O.orb_detect_and_compute(fr, 300)
+    pts = np.stack([k["x"], k["y"]], 1)[:150]
+    p, s, e = O.lk_track(fr, fr, pts)
+    assert s.all() and np.abs(p - pts).max() < 1e-3 and e.max() == 0
+    shifted = np.roll(fr, (2, 3), (0, 1))                           # content moves +3 px in x, +2 px in y
+    p, s, e = O.lk_track(fr, shifted, pts)
+    inner = (pts[:, 0] > 40) & (pts[:, 0] < 280) & (pts[:, 1] > 40) & (pts[:, 1] < 200) & (s > 0)
+    assert inner.sum() > 50 and np.abs(np.median(p[inner] - pts[inner], 0) - [3, 2]).max() < 0.05
+    # cn scales every integer sum exactly; only the minEig gate (no cn in its denominator) and float rounding change
+    p1, s1, e1 = O.lk_track(fr, shifted, pts, cn=1)
+    assert np.all(s1 <= s) and np.abs(p1[s1 > 0] - p[s1 > 0]).max() < 1e-3
+
+
+# ---- linear algebra ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(3, 3), (4, 4), (7, 9), (12, 12), (6, 4), (6, 5), (5, 9)])
+def test_jacobi_svd_vs_numpy(shape):
+    A = np.random.default_rng(sum(shape)).normal(size=shape)
+    U, w, Vt = O.svd(A, full=True)
+    assert np.abs(w - np.linalg.svd(A)[1]).max() < 1e-12
+    k = min(shape)
+    assert np.abs((U[:, :k] * w) @ Vt[:k] - A).max() < 1e-12 and np.abs(Vt @ Vt.T - np.eye(len(Vt))).max() < 1e-12
+
+
+def test_jacobi_eigen_and_cubic():
+    S = np.random.default_rng(3).normal(size=(9, 9))
+    S = S @ S.T
+    W, V = O.eigen_sym(S)
+    assert np.abs(W - np.linalg.eigvalsh(S)[::-1]).max() < 1e-11 and np.abs(V @ S @ V.T - np.diag(W)).max() < 1e-10
+    n, x = O.solve_cubic([1, -6, 11, -6])
+    assert n == 3 and sorted(np.round(x, 9)) == [1, 2, 3]
+    n, x = O.solve_cubic([2, 0, 0, -16])
+    assert n == 1 and abs(x[0] - 2) < 1e-12
+    n, x = O.solve_cubic([0, 1, -3, 2])
+    assert n == 2 and sorted(np.round(x[:2], 12)) == [1, 2]
+
+
+# ---- planted-ground-truth geometry -----------------------------------------------------------------------------
+def test_homography_recovers_planted_plane():
+    sc = synth.gen_scene(500, 11, planar=True, noise_px=0.0, outlier_frac=0.2)
+    r, mask, H, st = O.find_homography_ransac(sc["p1"], sc["p2"], 1.0)
+    assert np.array_equal(mask.astype(bool), sc["inlier"])           # outliers are >> threshold away
+    p = np.c_[sc["p1"][sc["inlier"]], np.ones(sc["inlier"].sum())] @ H.T
+    assert np.abs(p[:, :2] / p[:, 2:] - sc["p2"][sc["inlier"]]).max() < 1e-2
+
+
+def test_fundamental_and_essential_recover_planted_motion():
+    sc = synth.gen_scene(600, 12, noise_px=0.0, outlier_frac=0.2)
+    K, R, t = sc["K"], sc["R"], sc["t"]
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    Ki = np.linalg.inv(K)
+    Fgt = Ki.T @ tx @ R @ Ki
+    r, mask, F, st = O.find_fundamental_ransac(sc["p1"], sc["p2"], 1.0, 0.99)
+    assert mask[sc["inlier"]].mean() > 0.99 and mask[~sc["inlier"]].sum() <= 6   # an outlier can sit near its epipolar line
+    assert np.abs(F / F[2, 2] - Fgt / Fgt[2, 2]).max() < 1e-3 * np.abs(Fgt / Fgt[2, 2]).max() + 1e-9
+    r, mask, E, st = O.find_essential_ransac(sc["p1"], sc["p2"], K, 0.99, 1.0)
+    assert mask[sc["inlier"]].mean() > 0.99
+    Egt = tx @ R
+    Egt /= np.linalg.norm(Egt)
+    assert min(np.abs(E - Egt).max(), np.abs(E + Egt).max()) < 1e-4
+    g, Rr, tr, m = O.recover_pose(E, sc["p1"], sc["p2"], K, mask=mask)
+    assert np.abs(Rr - R).max() < 1e-4 and np.abs(tr - t / np.linalg.norm(t)).max() < 1e-3
+    assert g > 0 and m.sum() == g
+
+
+def test_pnp_recovers_planted_pose():
+    for planar in (False, True):
+        sc = synth.gen_scene(400, 13 + planar, planar=planar, noise_px=0.0, outlier_frac=0.2)
+        rc, r, t, idx, st = O.solve_pnp_ransac(sc["X"], sc["p2"], sc["K"])
+        inl = np.zeros(400, bool)
+        inl[idx] = True
+        assert rc == 1 and np.array_equal(inl, sc["inlier"])
+        assert np.abs(O.rodrigues(r) - sc["R"]).max() < 1e-6 and np.abs(t - sc["t"]).max() < 1e-4
+    assert np.abs(O.rodrigues(O.rodrigues(sc["R"])) - sc["R"]).max() < 1e-12    # Rodrigues round trip
+
+
+def test_triangulation_recovers_planted_points():
+    sc = synth.gen_scene(300, 15, noise_px=0.0, outlier_frac=0.0)
+    K = sc["K"]
+    P1 = K @ np.hstack([np.eye(3), np.zeros((3, 1))])
+    P2 = K @ np.hstack([sc["R"], sc["t"][:, None]])
+    X3, X4 = O.triangulate(P1, P2, sc["p1"], sc["p2"])
+    assert np.median(np.abs(X3 - sc["X"]) / np.abs(sc["X"]).max(1, keepdims=True)) < 5e-3   # float32 pixels, 0.3 m baseline
