@@ -695,51 +695,42 @@ void geom_state_destroy(mvo_ctx* ctx) {
 }
 
 template <class M>
-static void launch_ransac(mvo_ctx* ctx, int nslots, const float* m1, const float* m2, int stride1, int stride2, const int* d_n,
-                          double thr, double conf, int max_iters, const ModelParams& P, u8* mask, int mask_stride, double* model,
-                          int* result) {
+static void launch_ransac(mvo_ctx* ctx, hipStream_t st, int nslots, const float* m1, const float* m2, int stride1, int stride2,
+                          const int* d_n, double thr, double conf, int max_iters, const ModelParams& P, u8* mask, int mask_stride,
+                          double* model, int* result) {
   RansacArgs A;
   A.m1 = m1; A.m2 = m2; A.stride1 = stride1; A.stride2 = stride2; A.n = d_n;
   A.thr = thr; A.conf = conf; A.max_iters = max_iters; A.cap = ctx->maxpts; A.P = P;
   A.mask = mask; A.mask_stride = mask_stride; A.model = model; A.result = result;
-  hipLaunchKernelGGL(ransac_kernel<M>, dim3(nslots), dim3(256), 0, ctx->stream, A);
+  hipLaunchKernelGGL(ransac_kernel<M>, dim3(nslots), dim3(256), 0, st, A);
 }
 
 // Device-level drivers used by the pipeline (inputs already resident, all slots per launch).
 int geom_ransac_h(mvo_ctx* ctx, int nslots, const float* p1, const float* p2, const int* d_n, double thr, int max_iters, double conf,
-                  u8* mask, double* model, int* result) {
+                  u8* mask, double* model, int* result, hipStream_t st) {
+  if (!st) st = ctx->stream;
   ModelParams P{};
-  launch_ransac<HModel>(ctx, nslots, p1, p2, ctx->maxpts * 2, ctx->maxpts * 2, d_n, thr, conf, max_iters, P, mask, ctx->maxpts, model, result);
+  launch_ransac<HModel>(ctx, st, nslots, p1, p2, ctx->maxpts * 2, ctx->maxpts * 2, d_n, thr, conf, max_iters, P, mask, ctx->maxpts, model, result);
   return MVO_OK;
 }
 int geom_ransac_f(mvo_ctx* ctx, int nslots, const float* p1, const float* p2, const int* d_n, double thr, int max_iters, double conf,
-                  u8* mask, double* model, int* result) {
+                  u8* mask, double* model, int* result, hipStream_t st) {
+  if (!st) st = ctx->stream;
   ModelParams P{};
-  launch_ransac<FModel>(ctx, nslots, p1, p2, ctx->maxpts * 2, ctx->maxpts * 2, d_n, thr, conf, max_iters, P, mask, ctx->maxpts, model, result);
+  launch_ransac<FModel>(ctx, st, nslots, p1, p2, ctx->maxpts * 2, ctx->maxpts * 2, d_n, thr, conf, max_iters, P, mask, ctx->maxpts, model, result);
   return MVO_OK;
 }
-static void dbg_sync(mvo_ctx* ctx, const char* what) {
-  static int on = -1;
-  if (on < 0) on = getenv("MVO_DEBUG_SYNC") ? 1 : 0;
-  if (!on) return;
-  fprintf(stderr, "[mvo] launched %s ...", what); fflush(stderr);
-  hipError_t e = hipStreamSynchronize(ctx->stream);
-  fprintf(stderr, " done (%s)\n", hipGetErrorString(e)); fflush(stderr);
-}
-
 int geom_pnp(mvo_ctx* ctx, int nslots, const float* obj, const float* img, const int* d_n, const double K[9], int iters, float reproj,
-             double conf, u8* mask, double* model, int* result, int* inl, double* pose) {
+             double conf, u8* mask, double* model, int* result, int* inl, double* pose, hipStream_t st) {
+  if (!st) st = ctx->stream;
   ModelParams P{};
   P.cam = CamK{K[0], K[4], K[2], K[5]};
-  launch_ransac<PnPModel>(ctx, nslots, obj, img, ctx->maxpts * 3, ctx->maxpts * 2, d_n, (double)reproj, conf, iters, P, mask, ctx->maxpts,
+  launch_ransac<PnPModel>(ctx, st, nslots, obj, img, ctx->maxpts * 3, ctx->maxpts * 2, d_n, (double)reproj, conf, iters, P, mask, ctx->maxpts,
                           model, result);
-  dbg_sync(ctx, "ransac_kernel<PnP>");
-  hipLaunchKernelGGL(mask_to_indices_kernel, dim3(nslots), dim3(1024), 0, ctx->stream, mask, ctx->maxpts, d_n, inl, ctx->maxpts, result);
+  hipLaunchKernelGGL(mask_to_indices_kernel, dim3(nslots), dim3(1024), 0, st, mask, ctx->maxpts, d_n, inl, ctx->maxpts, result);
   PnpRefineArgs R;
   R.obj = obj; R.img = img; R.stride_pts = ctx->maxpts; R.inl = inl; R.result = result; R.model = model; R.n = d_n; R.pose = pose; R.cam = P.cam;
-  dbg_sync(ctx, "mask_to_indices");
-  hipLaunchKernelGGL(pnp_refine_kernel, dim3(nslots), dim3(PR_T), 0, ctx->stream, R);
-  dbg_sync(ctx, "pnp_refine_kernel");
+  hipLaunchKernelGGL(pnp_refine_kernel, dim3(nslots), dim3(PR_T), 0, st, R);
   return MVO_OK;
 }
 
@@ -833,7 +824,7 @@ extern "C" int mvo_find_homography_ransac(mvo_ctx* ctx, const float* p1, const f
   GeomState* g = ctx->geom;
   int rc = upload_pairs(ctx, p1, 2, p2, 2, n);
   if (rc) return rc;
-  geom_ransac_h(ctx, 1, g->d_m1, g->d_m2, g->d_n, thr, max_iters, confidence, g->d_mask, g->d_model, g->d_result);
+  geom_ransac_h(ctx, 1, g->d_m1, g->d_m2, g->d_n, thr, max_iters, confidence, g->d_mask, g->d_model, g->d_result, nullptr);
   MVO_HIP(hipMemcpyAsync(mask, g->d_mask, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   MVO_HIP(hipMemcpyAsync(g->h_model, g->d_model, 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MVO_HIP(hipMemcpyAsync(g->h_result, g->d_result, 8 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -855,7 +846,7 @@ extern "C" int mvo_find_fundamental_ransac(mvo_ctx* ctx, const float* p1, const 
   GeomState* g = ctx->geom;
   int rc = upload_pairs(ctx, p1, 2, p2, 2, n);
   if (rc) return rc;
-  geom_ransac_f(ctx, 1, g->d_m1, g->d_m2, g->d_n, thr, max_iters, confidence, g->d_mask, g->d_model, g->d_result);
+  geom_ransac_f(ctx, 1, g->d_m1, g->d_m2, g->d_n, thr, max_iters, confidence, g->d_mask, g->d_model, g->d_result, nullptr);
   MVO_HIP(hipMemcpyAsync(mask, g->d_mask, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   MVO_HIP(hipMemcpyAsync(g->h_model, g->d_model, 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MVO_HIP(hipMemcpyAsync(g->h_result, g->d_result, 8 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -878,7 +869,7 @@ extern "C" int mvo_solve_pnp_ransac(mvo_ctx* ctx, const float* obj, const float*
   GeomState* g = ctx->geom;
   int rc = upload_pairs(ctx, obj, 3, img, 2, n);
   if (rc) return rc;
-  geom_pnp(ctx, 1, g->d_m1, g->d_m2, g->d_n, K, iters, reproj_err, confidence, g->d_mask, g->d_model, g->d_result, g->d_inl, g->d_pose);
+  geom_pnp(ctx, 1, g->d_m1, g->d_m2, g->d_n, K, iters, reproj_err, confidence, g->d_mask, g->d_model, g->d_result, g->d_inl, g->d_pose, nullptr);
   MVO_HIP(hipMemcpyAsync(g->h_model, g->d_pose, 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MVO_HIP(hipMemcpyAsync(g->h_result, g->d_result, 8 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   MVO_HIP(hipStreamSynchronize(ctx->stream));

@@ -8,9 +8,11 @@
 //                    wave stages the 24x24 source neighbourhood of the previous image in LDS, derives the
 //                    22x22 Scharr field there, and keeps its 21x21 fixed-point template (I, Ix, Iy) in
 //                    registers: 63 lanes x 7 horizontally adjacent pixels.  The search window of the next
-//                    image is staged as a 32x32 LDS tile that is re-fetched only when the window leaves it.
-//                    Normal-equation sums are exact integers (per-lane int32 partials, int64 wave reduction),
-//                    so results are independent of summation order and bit-identical to the oracle.
+//                    image is staged as a 32x32 LDS tile (aligned dword loads; re-fetched only when the window
+//                    leaves it).  The inner loop reads two unaligned 8-byte spans as dwords + v_alignbyte,
+//                    packs pixel pairs with v_perm and evaluates the 14-bit bilinear sum with v_dot2c_i32_i16.
+//                    Normal-equation sums are exact integers: int32 per lane, DPP wave reduction of a 16/16
+//                    split, so results are independent of summation order and bit-identical to the oracle.
 #include "mvo_internal.h"
 
 // ---------------------------------------------------------------------------------------------------
@@ -82,15 +84,30 @@ struct LkArgs {
 
 #define LK_WIN 21
 #define LK_IT 24          // I tile edge (WIN + 1 bilinear + 2 Scharr halo)
+#define LK_IP 28          // I tile pitch: 7 dwords cover 24 bytes at any 4-byte phase
 #define LK_DT 22          // derivative tile edge
 #define LK_JT 32          // J tile edge
-#define LK_JP 36          // J tile pitch (bytes)
+#define LK_JP 36          // J tile pitch: 9 dwords cover 32 bytes at any 4-byte phase
 #define LK_JSLACK ((LK_JT - (LK_WIN + 1)) / 2)
 
-__device__ __forceinline__ long long wave_sum_i64(long long v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
+typedef short lk_short2 __attribute__((ext_vector_type(2)));
+
+// Wave-wide integer sum with DPP adds (no LDS traffic, ~6 dependent VALU ops) -> value in every lane.
+__device__ __forceinline__ int wave_sum_i32_dpp(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);  // row_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);  // row_bcast:15 -> rows 1,3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);  // row_bcast:31 -> rows 2,3
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+// Exact 64-bit wave sum of int32 partials: split into a signed high part and an unsigned 16-bit low part,
+// each of which sums without overflow in 32 bits across 64 lanes.
+__device__ __forceinline__ long long wave_sum_exact(int v) {
+  int lo = v & 0xFFFF, hi = v >> 16;
+  return (long long)wave_sum_i32_dpp(hi) * 65536LL + (long long)wave_sum_i32_dpp(lo);
 }
 
 __device__ __forceinline__ void lk_weights(float a, float b, int& w00, int& w01, int& w10, int& w11) {
@@ -104,46 +121,62 @@ __device__ __forceinline__ void lk_weights(float a, float b, int& w00, int& w01,
 __device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
 
 struct LkWaveLds {
-  u8 it[LK_IT * LK_IT];          // previous-image neighbourhood
-  short2 dt[LK_DT * LK_DT];      // Scharr (dx, dy)
-  u8 jt[LK_JT * LK_JP];          // next-image search tile
+  unsigned it[LK_IT * LK_IP / 4];   // previous-image neighbourhood (rows of 28 bytes)
+  short2 dt[LK_DT * LK_DT];         // Scharr (dx, dy)
+  unsigned jt[LK_JT * LK_JP / 4];   // next-image search tile (rows of 36 bytes)
 };
 
-__device__ __forceinline__ void load_j_tile(u8* jt, const u8* J, int w, int h, int pitch, int jx0, int jy0,
-                                            int lane) {
-  // 32 x 32 bytes, reflect-101 on both axes; 16 bytes per lane.
-  int row = lane >> 1, c0 = (lane & 1) * 16;
-  int sy = d_reflect101(jy0 + row, h);
-  const u8* rp = J + (size_t)sy * pitch;
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    int sx = d_reflect101(jx0 + c0 + i, w);
-    jt[row * LK_JP + c0 + i] = rp[sx];
+// Stage ROWS x TW bytes of the image starting at (x0, y0) into LDS rows of NDW dwords.  Fast path: the
+// tile lies inside the image -> aligned dword loads, the tile starts `shift` bytes into each LDS row.
+// Slow path (image border): per-byte reflect-101.  Returns the byte shift (wave-uniform).
+template <int ROWS, int TW, int NDW>
+__device__ __forceinline__ int lk_load_tile(unsigned* lds, const u8* __restrict__ img, int w, int h, int pitch, int x0, int y0, int lane) {
+  const int xa = x0 & ~3;
+  const bool inside = x0 >= 0 && y0 >= 0 && x0 + TW <= w && y0 + ROWS <= h && xa + 4 * NDW <= pitch;
+  if (inside) {
+    const u8* base = img + (size_t)y0 * pitch + xa;
+    for (int i = lane; i < ROWS * NDW; i += 64) {
+      int row = i / NDW, k = i - row * NDW;
+      lds[i] = *(const unsigned*)(base + (size_t)row * pitch + 4 * k);
+    }
+    return x0 - xa;
   }
+  u8* lb = (u8*)lds;
+  for (int i = lane; i < ROWS * TW; i += 64) {
+    int row = i / TW, col = i - row * TW;
+    int gx = d_reflect101(x0 + col, w), gy = d_reflect101(y0 + row, h);
+    lb[row * (NDW * 4) + col] = img[(size_t)gy * pitch + gx];
+  }
+  return 0;
 }
 
-// sum over the lane's 7 pixels of J(bilinear) - I, times (Ix, Iy) or abs.
+// One lane's 7 pixels of (bilinear J - I) against (Ix, Iy) or |.|: two unaligned 8-byte row spans are read
+// as 3 dwords each and re-aligned with v_alignbyte; v_perm builds (p_k, p_k+1) 16-bit pairs and two
+// v_dot2c_i32_i16 evaluate the 4-tap fixed-point bilinear sum exactly.
 template <bool ERR>
-__device__ __forceinline__ void lk_accumulate(const u8* jt, int dx, int dy, int r, int x0, bool active,
-                                              int w00, int w01, int w10, int w11, const int* Iv,
+__device__ __forceinline__ void lk_accumulate(const unsigned* jt, int byte_off, bool active, unsigned W0, unsigned W1, const int* Iv,
                                               const int* Ixv, const int* Iyv, int& s1, int& s2) {
   s1 = 0; s2 = 0;
   if (!active) return;
-  const u8* p0 = jt + (r + dy) * LK_JP + x0 + dx;
-  const u8* p1 = p0 + LK_JP;
-  int a0 = p0[0], b0 = p1[0];
-#pragma unroll
-  for (int i = 0; i < 7; i++) {
-    int a1 = p0[i + 1], b1 = p1[i + 1];
-    int diff = descale(a0 * w00 + a1 * w01 + b0 * w10 + b1 * w11, 14 - 5) - Iv[i];
-    if (ERR) {
-      s1 += abs(diff);
-    } else {
-      s1 += diff * Ixv[i];
-      s2 += diff * Iyv[i];
-    }
-    a0 = a1; b0 = b1;
+  const int sh = byte_off & 3;
+  const unsigned* q = jt + (byte_off >> 2);
+  unsigned a0 = q[0], a1 = q[1], a2 = q[2];
+  unsigned b0 = q[LK_JP / 4], b1 = q[LK_JP / 4 + 1], b2 = q[LK_JP / 4 + 2];
+  unsigned r0lo = __builtin_amdgcn_alignbyte(a1, a0, sh), r0hi = __builtin_amdgcn_alignbyte(a2, a1, sh);
+  unsigned r1lo = __builtin_amdgcn_alignbyte(b1, b0, sh), r1hi = __builtin_amdgcn_alignbyte(b2, b1, sh);
+  const lk_short2 w0 = __builtin_bit_cast(lk_short2, W0), w1 = __builtin_bit_cast(lk_short2, W1);
+#define LK_PIX(k)                                                                                                   \
+  {                                                                                                                 \
+    const unsigned sel = (unsigned)(k) | (0x0Cu << 8) | ((unsigned)((k) + 1) << 16) | (0x0Cu << 24);               \
+    unsigned p0 = __builtin_amdgcn_perm(r0hi, r0lo, sel), p1 = __builtin_amdgcn_perm(r1hi, r1lo, sel);             \
+    int acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_short2, p0), w0, 0, false);                              \
+    acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_short2, p1), w1, acc, false);                                \
+    int diff = ((acc + (1 << 8)) >> 9) - Iv[k];                                                                     \
+    if (ERR) { s1 += abs(diff); }                                                                                   \
+    else { s1 += __mul24(diff, Ixv[k]); s2 += __mul24(diff, Iyv[k]); }                                              \
   }
+  LK_PIX(0) LK_PIX(1) LK_PIX(2) LK_PIX(3) LK_PIX(4) LK_PIX(5) LK_PIX(6)
+#undef LK_PIX
 }
 
 __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs A) {
@@ -180,24 +213,22 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs A) {
       if (level == 0) { status = 0; errv = 0.f; }
       continue;
     }
-    // ---- stage the 24x24 neighbourhood of I (origin ipx-1, ipy-1), reflect-101 -------------------
-    for (int i = lane; i < LK_IT * LK_IT; i += 64) {
-      int ty = i / LK_IT, tx = i - ty * LK_IT;
-      int gx = d_reflect101(ipx - 1 + tx, lv.w), gy = d_reflect101(ipy - 1 + ty, lv.h);
-      S.it[i] = I[(size_t)gy * lv.pitch + gx];
-    }
+    // ---- stage the 24x24 neighbourhood of I (origin ipx-1, ipy-1) -------------------------------------
     __builtin_amdgcn_wave_barrier();
+    const int shI = lk_load_tile<LK_IT, LK_IT, LK_IP / 4>(S.it, I, lv.w, lv.h, lv.pitch, ipx - 1, ipy - 1, lane);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const u8* itb = (const u8*)S.it + shI;
     // ---- Scharr field on the 22x22 window-source positions (zero outside the image) --------------
     for (int i = lane; i < LK_DT * LK_DT; i += 64) {
       int ty = i / LK_DT, tx = i - ty * LK_DT;
       int gx = ipx + tx, gy = ipy + ty;
       short2 d = make_short2(0, 0);
       if ((unsigned)gx < (unsigned)lv.w && (unsigned)gy < (unsigned)lv.h) {
-        const u8* c = &S.it[(ty + 1) * LK_IT + tx + 1];
-        int l0 = c[-LK_IT - 1], l1 = c[-1], l2 = c[LK_IT - 1];
-        int m0 = c[-LK_IT], m2 = c[LK_IT];
-        int r0 = c[-LK_IT + 1], r1 = c[1], r2 = c[LK_IT + 1];
+        const u8* c = itb + (ty + 1) * LK_IP + tx + 1;
+        int l0 = c[-LK_IP - 1], l1 = c[-1], l2 = c[LK_IP - 1];
+        int m0 = c[-LK_IP], m2 = c[LK_IP];
+        int r0 = c[-LK_IP + 1], r1 = c[1], r2 = c[LK_IP + 1];
         int t0r = (r0 + r2) * 3 + r1 * 10, t0l = (l0 + l2) * 3 + l1 * 10;
         int t1l = l2 - l0, t1m = m2 - m0, t1r = r2 - r0;
         d.x = (short)(t0r - t0l);
@@ -205,32 +236,32 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs A) {
       }
       S.dt[i] = d;
     }
-    __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     // ---- template in registers + exact A sums ---------------------------------------------------------
     int w00, w01, w10, w11;
     lk_weights(px - ipx, py - ipy, w00, w01, w10, w11);
     int Iv[7], Ixv[7], Iyv[7];
     int a11 = 0, a12 = 0, a22 = 0;
     if (active) {
-      const u8* i0 = &S.it[(r + 1) * LK_IT + x0 + 1];
-      const u8* i1 = i0 + LK_IT;
+      const u8* i0 = itb + (r + 1) * LK_IP + x0 + 1;
+      const u8* i1 = i0 + LK_IP;
       const short2* d0 = &S.dt[r * LK_DT + x0];
       const short2* d1 = d0 + LK_DT;
 #pragma unroll
       for (int i = 0; i < 7; i++) {
-        Iv[i] = descale(i0[i] * w00 + i0[i + 1] * w01 + i1[i] * w10 + i1[i + 1] * w11, 14 - 5);
+        Iv[i] = descale(__mul24(i0[i], w00) + __mul24(i0[i + 1], w01) + __mul24(i1[i], w10) + __mul24(i1[i + 1], w11), 14 - 5);
         short2 e00 = d0[i], e01 = d0[i + 1], e10 = d1[i], e11 = d1[i + 1];
-        int ix = descale(e00.x * w00 + e01.x * w01 + e10.x * w10 + e11.x * w11, 14);
-        int iy = descale(e00.y * w00 + e01.y * w01 + e10.y * w10 + e11.y * w11, 14);
+        int ix = descale(__mul24(e00.x, w00) + __mul24(e01.x, w01) + __mul24(e10.x, w10) + __mul24(e11.x, w11), 14);
+        int iy = descale(__mul24(e00.y, w00) + __mul24(e01.y, w01) + __mul24(e10.y, w10) + __mul24(e11.y, w11), 14);
         Ixv[i] = ix; Iyv[i] = iy;
-        a11 += ix * ix; a12 += ix * iy; a22 += iy * iy;
+        a11 += __mul24(ix, ix); a12 += __mul24(ix, iy); a22 += __mul24(iy, iy);
       }
     } else {
 #pragma unroll
       for (int i = 0; i < 7; i++) { Iv[i] = 0; Ixv[i] = 0; Iyv[i] = 0; }
     }
-    long long sA11 = wave_sum_i64(a11), sA12 = wave_sum_i64(a12), sA22 = wave_sum_i64(a22);
+    long long sA11 = wave_sum_exact(a11), sA12 = wave_sum_exact(a12), sA22 = wave_sum_exact(a22);
     float A11 = (float)(sA11 * A.cn) * FLT_SCALE;
     float A12 = (float)(sA12 * A.cn) * FLT_SCALE;
     float A22 = (float)(sA22 * A.cn) * FLT_SCALE;
@@ -244,7 +275,7 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs A) {
     D = 1.f / D;
     nx -= half; ny -= half;
     float pdx = 0.f, pdy = 0.f;
-    int jx0 = 0, jy0 = 0;
+    int jx0 = 0, jy0 = 0, shJ = 0;
     bool have_tile = false;
     for (int j = 0; j < A.max_count; j++) {
       int inx = d_cv_floor(nx), iny = d_cv_floor(ny);
@@ -256,7 +287,7 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs A) {
       if (!have_tile || ddx < 0 || ddx > LK_JT - (LK_WIN + 1) || ddy < 0 || ddy > LK_JT - (LK_WIN + 1)) {
         jx0 = inx - LK_JSLACK; jy0 = iny - LK_JSLACK;
         __builtin_amdgcn_wave_barrier();
-        load_j_tile(S.jt, J, lv.w, lv.h, lv.pitch, jx0, jy0, lane);
+        shJ = lk_load_tile<LK_JT, LK_JT, LK_JP / 4>(S.jt, J, lv.w, lv.h, lv.pitch, jx0, jy0, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         have_tile = true;
@@ -264,8 +295,9 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs A) {
       }
       lk_weights(nx - inx, ny - iny, w00, w01, w10, w11);
       int s1, s2;
-      lk_accumulate<false>(S.jt, ddx, ddy, r, x0, active, w00, w01, w10, w11, Iv, Ixv, Iyv, s1, s2);
-      long long sb1 = wave_sum_i64(s1), sb2 = wave_sum_i64(s2);
+      lk_accumulate<false>(S.jt, (r + ddy) * LK_JP + x0 + ddx + shJ, active, (unsigned)w00 | ((unsigned)w01 << 16),
+                           (unsigned)w10 | ((unsigned)w11 << 16), Iv, Ixv, Iyv, s1, s2);
+      long long sb1 = wave_sum_exact(s1), sb2 = wave_sum_exact(s2);
       float b1 = (float)(sb1 * A.cn) * FLT_SCALE;
       float b2 = (float)(sb2 * A.cn) * FLT_SCALE;
       float dx = (A12 * b2 - A22 * b1) * D;
@@ -290,15 +322,16 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs A) {
         if (!have_tile || ddx < 0 || ddx > LK_JT - (LK_WIN + 1) || ddy < 0 || ddy > LK_JT - (LK_WIN + 1)) {
           jx0 = inx - LK_JSLACK; jy0 = iny - LK_JSLACK;
           __builtin_amdgcn_wave_barrier();
-          load_j_tile(S.jt, J, lv.w, lv.h, lv.pitch, jx0, jy0, lane);
+          shJ = lk_load_tile<LK_JT, LK_JT, LK_JP / 4>(S.jt, J, lv.w, lv.h, lv.pitch, jx0, jy0, lane);
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           ddx = LK_JSLACK; ddy = LK_JSLACK;
         }
         lk_weights(ex - inx, ey - iny, w00, w01, w10, w11);
         int s1, s2;
-        lk_accumulate<true>(S.jt, ddx, ddy, r, x0, active, w00, w01, w10, w11, Iv, Ixv, Iyv, s1, s2);
-        long long se = wave_sum_i64(s1);
+        lk_accumulate<true>(S.jt, (r + ddy) * LK_JP + x0 + ddx + shJ, active, (unsigned)w00 | ((unsigned)w01 << 16),
+                            (unsigned)w10 | ((unsigned)w11 << 16), Iv, Ixv, Iyv, s1, s2);
+        long long se = wave_sum_exact(s1);
         float errval = (float)(se * A.cn);
         errv = errval * 1.f / (float)(32 * LK_WIN * A.cn * LK_WIN);
       }

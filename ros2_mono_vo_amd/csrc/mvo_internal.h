@@ -73,11 +73,11 @@ struct mvo_ctx {
 };
 
 // Stage timers (HIP events on ctx->stream).
-void prof_begin(mvo_ctx* ctx, const char* name);
+void prof_begin(mvo_ctx* ctx, const char* name, hipStream_t st = nullptr);
 void prof_end(mvo_ctx* ctx);
 struct ProfScope {
   mvo_ctx* c;
-  ProfScope(mvo_ctx* ctx, const char* name) : c(ctx) { prof_begin(c, name); }
+  ProfScope(mvo_ctx* ctx, const char* name, hipStream_t st = nullptr) : c(ctx) { prof_begin(c, name, st); }
   ~ProfScope() { prof_end(c); }
 };
 
@@ -185,11 +185,11 @@ int lk_track_device(mvo_ctx* ctx, int prev_set, int cur_set, const LkLevels& L, 
 int orb_run(mvo_ctx* ctx, int w, int h, int nslots, bool describe, std::vector<int>& kp_base);
 int match_device(mvo_ctx* ctx, int nslots, int max_nq, double ratio);
 int geom_ransac_h(mvo_ctx* ctx, int nslots, const float* p1, const float* p2, const int* d_n, double thr, int max_iters, double conf,
-                  u8* mask, double* model, int* result);
+                  u8* mask, double* model, int* result, hipStream_t st);
 int geom_ransac_f(mvo_ctx* ctx, int nslots, const float* p1, const float* p2, const int* d_n, double thr, int max_iters, double conf,
-                  u8* mask, double* model, int* result);
+                  u8* mask, double* model, int* result, hipStream_t st);
 int geom_pnp(mvo_ctx* ctx, int nslots, const float* obj, const float* img, const int* d_n, const double K[9], int iters, float reproj,
-             double conf, u8* mask, double* model, int* result, int* inl, double* pose);
+             double conf, u8* mask, double* model, int* result, int* inl, double* pose, hipStream_t st);
 int geom_triangulate_matches(mvo_ctx* ctx, int nslots, int max_matches, const mvo_match* matches, const int* n_matches,
                              const float* kf_xy, const float* cur_xy, const double* kf_pose, const double* cur_pose,
                              const int* pnp_result, const double K[9], float* X3, u8* valid);

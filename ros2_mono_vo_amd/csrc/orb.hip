@@ -17,7 +17,9 @@
 #include "mvo_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <thread>
 
 static const int kOrbPattern31[256 * 4] = {
 #include "orb_pattern_31.inc"
@@ -640,10 +642,12 @@ int orb_run(mvo_ctx* ctx, int w, int h, int nslots, bool describe, std::vector<i
   MVO_HIP(hipMemcpyAsync(o->h_ch, o->d_ch, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, st));
   MVO_HIP(hipStreamSynchronize(st));
   // ---- host: OpenCV's two retainBest passes per level, on responses only ---------------------------
-  int nsel = 0;
-  std::vector<RespIdx> k;
-  for (int s = 0; s < nslots; s++) {
-    kp_base[s] = nsel;
+  // Streams are independent, so the per-slot selections run on a few host threads; the selected candidate
+  // indices are then concatenated in slot order.
+  std::vector<std::vector<int>> picked(nslots);
+  auto select_slot = [&](int s) {
+    std::vector<RespIdx> k;
+    std::vector<int>& out = picked[s];
     int off = sbase[s];
     for (int l = 0; l < G.nlevels; l++) {
       int cnt = lvl[s * MVO_ORB_LEVELS + l];
@@ -652,10 +656,28 @@ int orb_run(mvo_ctx* ctx, int w, int h, int nslots, bool describe, std::vector<i
       retain_best(k, 2 * G.quota[l]);
       for (auto& e : k) e.response = o->h_ch[e.idx];
       retain_best(k, G.quota[l]);
-      if (nsel + (int)k.size() > o->kp_cap) { ctx->set_error("ORB key-point capacity exceeded"); return MVO_E_CAPACITY; }
-      for (auto& e : k) o->h_sel[nsel++] = e.idx;
+      for (auto& e : k) out.push_back(e.idx);
       off += cnt;
     }
+  };
+  {
+    int nthreads = (int)std::min<size_t>({(size_t)nslots, (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)16});
+    if (nthreads <= 1) {
+      for (int s = 0; s < nslots; s++) select_slot(s);
+    } else {
+      std::atomic<int> next{0};
+      std::vector<std::thread> pool;
+      for (int t = 0; t < nthreads; t++)
+        pool.emplace_back([&]() { for (int s = next.fetch_add(1); s < nslots; s = next.fetch_add(1)) select_slot(s); });
+      for (auto& th : pool) th.join();
+    }
+  }
+  int nsel = 0;
+  for (int s = 0; s < nslots; s++) {
+    kp_base[s] = nsel;
+    if (nsel + (int)picked[s].size() > o->kp_cap) { ctx->set_error("ORB key-point capacity exceeded"); return MVO_E_CAPACITY; }
+    memcpy(o->h_sel + nsel, picked[s].data(), picked[s].size() * sizeof(int));
+    nsel += (int)picked[s].size();
   }
   kp_base[nslots] = nsel;
   if (nsel == 0) return MVO_OK;

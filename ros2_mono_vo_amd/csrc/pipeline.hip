@@ -15,7 +15,7 @@
 // ---------------------------------------------------------------------------------------------------
 struct Prof {
   bool on = false;
-  struct Pending { std::string name; hipEvent_t a, b; };
+  struct Pending { std::string name; hipEvent_t a, b; hipStream_t st; };
   std::vector<Pending> pending;
   std::vector<hipEvent_t> pool;
   std::map<std::string, std::pair<double, int>> acc;
@@ -29,12 +29,12 @@ static hipEvent_t prof_event(Prof* p) {
   return e;
 }
 
-void prof_begin(mvo_ctx* ctx, const char* name) {
+void prof_begin(mvo_ctx* ctx, const char* name, hipStream_t st) {
   Prof* p = ctx->prof;
   if (!p || !p->on) return;
   Prof::Pending q;
-  q.name = name; q.a = prof_event(p); q.b = prof_event(p);
-  (void)hipEventRecord(q.a, ctx->stream);
+  q.name = name; q.a = prof_event(p); q.b = prof_event(p); q.st = st ? st : ctx->stream;
+  (void)hipEventRecord(q.a, q.st);
   p->open.push_back(q);
 }
 
@@ -43,7 +43,7 @@ void prof_end(mvo_ctx* ctx) {
   if (!p || !p->on || p->open.empty()) return;
   Prof::Pending q = p->open.back();
   p->open.pop_back();
-  (void)hipEventRecord(q.b, ctx->stream);
+  (void)hipEventRecord(q.b, q.st);
   p->pending.push_back(q);
 }
 
@@ -52,6 +52,7 @@ static void prof_collect(mvo_ctx* ctx) {
   if (!p) return;
   (void)hipStreamSynchronize(ctx->stream);
   for (auto& q : p->pending) {
+    (void)hipEventSynchronize(q.b);
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, q.a, q.b) == hipSuccess) {
       auto& e = p->acc[q.name];
@@ -116,6 +117,9 @@ struct PipeState {
   u8* d_tri_ok = nullptr;     // [B][maxpts]
   double* d_kf_pose = nullptr;  // [B][8] T_cw of the last key-frame (rvec, tvec)
   int* d_ntri = nullptr;      // [B]
+  // side streams: the latency-bound RANSAC chains run beside ORB (they only depend on the LK survivors)
+  hipStream_t s_pnp = nullptr, s_hf = nullptr;
+  hipEvent_t ev_lk = nullptr, ev_pnp = nullptr, ev_hf = nullptr;
   int trk_max_n = 0;  // host-side bound on the per-slot track count (grid sizing)
   int kf_max_n = 0;   // host-side bound on the key-frame descriptor count
 };
@@ -147,6 +151,11 @@ int pipe_state_create(mvo_ctx* ctx) {
   MVO_HIP(hipMalloc(&p->d_tri_ok, np));
   MVO_HIP(hipMalloc(&p->d_kf_pose, (size_t)ctx->B * 8 * sizeof(double)));
   MVO_HIP(hipMalloc(&p->d_ntri, ctx->B * sizeof(int)));
+  MVO_HIP(hipStreamCreateWithFlags(&p->s_pnp, hipStreamNonBlocking));
+  MVO_HIP(hipStreamCreateWithFlags(&p->s_hf, hipStreamNonBlocking));
+  MVO_HIP(hipEventCreateWithFlags(&p->ev_lk, hipEventDisableTiming));
+  MVO_HIP(hipEventCreateWithFlags(&p->ev_pnp, hipEventDisableTiming));
+  MVO_HIP(hipEventCreateWithFlags(&p->ev_hf, hipEventDisableTiming));
   MVO_HIP(hipMemsetAsync(p->d_kf_has, 0, np, ctx->stream));
   MVO_HIP(hipMemsetAsync(p->d_kf_lm, 0, np * 3 * sizeof(float), ctx->stream));
   MVO_HIP(hipMemsetAsync(p->d_kf_pose, 0, (size_t)ctx->B * 8 * sizeof(double), ctx->stream));
@@ -163,6 +172,11 @@ void pipe_state_destroy(mvo_ctx* ctx) {
                    p->d_kf_has, p->d_kf_lm, p->d_cur_has, p->d_cur_lmk, p->d_winner, p->d_tri, p->d_tri_ok, p->d_kf_pose, p->d_ntri};
     for (void* q : dev) (void)hipFree(q);
     if (p->h_ints) (void)hipHostFree(p->h_ints);
+    if (p->s_pnp) { (void)hipStreamSynchronize(p->s_pnp); (void)hipStreamDestroy(p->s_pnp); }
+    if (p->s_hf) { (void)hipStreamSynchronize(p->s_hf); (void)hipStreamDestroy(p->s_hf); }
+    if (p->ev_lk) (void)hipEventDestroy(p->ev_lk);
+    if (p->ev_pnp) (void)hipEventDestroy(p->ev_pnp);
+    if (p->ev_hf) (void)hipEventDestroy(p->ev_hf);
     delete p;
     ctx->pipe = nullptr;
   }
@@ -487,20 +501,28 @@ extern "C" int mvo_batch_step(mvo_ctx* ctx, int frame_idx, unsigned stages, mvo_
   }
   const bool do_pnp = (stages & MVO_STAGE_LK) && (stages & MVO_STAGE_PNP);
   const bool do_hf = (stages & MVO_STAGE_LK) && (stages & MVO_STAGE_HF);
+  if (do_pnp || do_hf) MVO_HIP(hipEventRecord(p->ev_lk, ctx->stream));
   if (do_pnp) {
-    ProfScope ps(ctx, "pnp");
-    geom_pnp(ctx, B, p->d_cur_lm, p->d_cur_pts, p->d_ncur, p->K, 100, 8.0f, 0.99, g->d_mask, g->d_model, g->d_result, g->d_inl, g->d_pose);
-    MVO_HIP(hipMemcpyAsync(hr, g->d_result, (size_t)B * 8 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    MVO_HIP(hipMemcpyAsync(hp, g->d_pose, (size_t)B * 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MVO_HIP(hipStreamWaitEvent(p->s_pnp, p->ev_lk, 0));
+    { ProfScope ps(ctx, "pnp", p->s_pnp);
+      geom_pnp(ctx, B, p->d_cur_lm, p->d_cur_pts, p->d_ncur, p->K, 100, 8.0f, 0.99, g->d_mask, g->d_model, g->d_result, g->d_inl, g->d_pose,
+               p->s_pnp); }
+    MVO_HIP(hipMemcpyAsync(hr, g->d_result, (size_t)B * 8 * sizeof(int), hipMemcpyDeviceToHost, p->s_pnp));
+    MVO_HIP(hipMemcpyAsync(hp, g->d_pose, (size_t)B * 8 * sizeof(double), hipMemcpyDeviceToHost, p->s_pnp));
+    MVO_HIP(hipEventRecord(p->ev_pnp, p->s_pnp));
   }
   if (do_hf) {
     // Tracker::has_parallax: key-frame positions of the tracked landmarks vs their current positions
-    { ProfScope ps(ctx, "ransac_h");
-      geom_ransac_h(ctx, B, p->d_cur_kf, p->d_cur_pts, p->d_ncur, ctx->cfg.ransac_reproj_thresh, 2000, 0.995, g->d_mask2, g->d_model2, g->d_result2); }
-    MVO_HIP(hipMemcpyAsync(hr + 8 * B, g->d_result2, (size_t)B * 8 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    { ProfScope ps(ctx, "ransac_f");
-      geom_ransac_f(ctx, B, p->d_cur_kf, p->d_cur_pts, p->d_ncur, ctx->cfg.ransac_reproj_thresh, 1000, 0.99, g->d_mask2, g->d_model2, g->d_result2); }
-    MVO_HIP(hipMemcpyAsync(hr + 16 * B, g->d_result2, (size_t)B * 8 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MVO_HIP(hipStreamWaitEvent(p->s_hf, p->ev_lk, 0));
+    { ProfScope ps(ctx, "ransac_h", p->s_hf);
+      geom_ransac_h(ctx, B, p->d_cur_kf, p->d_cur_pts, p->d_ncur, ctx->cfg.ransac_reproj_thresh, 2000, 0.995, g->d_mask2, g->d_model2,
+                    g->d_result2, p->s_hf); }
+    MVO_HIP(hipMemcpyAsync(hr + 8 * B, g->d_result2, (size_t)B * 8 * sizeof(int), hipMemcpyDeviceToHost, p->s_hf));
+    { ProfScope ps(ctx, "ransac_f", p->s_hf);
+      geom_ransac_f(ctx, B, p->d_cur_kf, p->d_cur_pts, p->d_ncur, ctx->cfg.ransac_reproj_thresh, 1000, 0.99, g->d_mask2, g->d_model2,
+                    g->d_result2, p->s_hf); }
+    MVO_HIP(hipMemcpyAsync(hr + 16 * B, g->d_result2, (size_t)B * 8 * sizeof(int), hipMemcpyDeviceToHost, p->s_hf));
+    MVO_HIP(hipEventRecord(p->ev_hf, p->s_hf));
   }
   std::vector<int> base;
   if (stages & MVO_STAGE_ORB) {
@@ -515,6 +537,7 @@ extern "C" int mvo_batch_step(mvo_ctx* ctx, int frame_idx, unsigned stages, mvo_
       MVO_HIP(hipMemcpyAsync(hb + 2 * B, m->d_nout, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     }
     if (do_tri) {
+      MVO_HIP(hipStreamWaitEvent(ctx->stream, p->ev_pnp, 0));  // the pose comes from the PnP side stream
       ProfScope ps(ctx, "triangulate");
       int max_m = p->kf_max_n;  // matches <= queries
       geom_triangulate_matches(ctx, B, max_m, m->d_out, m->d_nout, p->d_kfkp_xy, p->d_kp_xy, p->d_kf_pose, g->d_pose, g->d_result, p->K,
@@ -540,6 +563,9 @@ extern "C" int mvo_batch_step(mvo_ctx* ctx, int frame_idx, unsigned stages, mvo_
     MVO_HIP(hipMemcpyAsync(p->d_kf_pts, p->d_cur_kf, np * 2 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     MVO_HIP(hipMemcpyAsync(ctx->d_npts, p->d_ncur, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
   }
+  // the LK survivors (d_cur_*) must not be overwritten by the next step before the side streams are done
+  if (do_pnp) MVO_HIP(hipStreamSynchronize(p->s_pnp));
+  if (do_hf) MVO_HIP(hipStreamSynchronize(p->s_hf));
   MVO_HIP(hipStreamSynchronize(ctx->stream));
   const bool tri_done = (stages & MVO_STAGE_ORB) && (stages & MVO_STAGE_MATCH) && do_pnp && (stages & MVO_STAGE_TRIANG);
   int mx_trk = 0;
