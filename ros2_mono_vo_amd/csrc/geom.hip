@@ -10,11 +10,11 @@
 // ransac_kernel<Model>: ONE WORKGROUP PER PROBLEM (camera stream), so a batch of B streams is B
 // workgroups in one launch.  OpenCV's loop is sequential (adaptive iteration count, "strictly better"
 // update, data-dependent RNG consumption), so each round does
-//   1. lane 0 draws up to 64 candidate samples from cv::RNG((uint64)-1) in OpenCV's order,
+//   1. lane 0 draws 64 candidate samples from cv::RNG((uint64)-1) in OpenCV's order,
 //   2. 64 lanes run checkSubset in parallel; an ordered ballot compaction turns passing candidates into
 //      RANSAC iterations (a failing candidate is exactly OpenCV's "retry with the next draws"),
 //   3. one hypothesis per lane: minimal solver (4-pt H / 7-pt F / 5-pt EPnP) in private memory,
-//   4. 256 lanes score: hypothesis = lane & 63, point quarter = lane >> 6; integer inlier counts,
+//   4. 256 lanes score (hypothesis = lane % 64, point quarter = lane / 64): integer inlier counts,
 //   5. lane 0 replays the hypotheses in order applying the consensus update and RANSACUpdateNumIters,
 // and stops as soon as iter >= niters — the speculative tail of a round is simply discarded, which is
 // unobservable because nothing after the loop reads the RNG.  The consensus mask is then recomputed for
@@ -39,7 +39,8 @@ struct RansacArgs {
   int* result;    // [B][8]: ok, n_inliers, iters_run, niters_final, models_scored
 };
 
-#define RS_CH 64
+#define RS_CH 64   // candidate samples per round (one wavefront of private solvers; wider rounds thrash L2 with scratch)
+#define RS_PARTS (256 / RS_CH)
 #ifndef RS_WAVES_PER_EU
 #define RS_WAVES_PER_EU 1
 #endif
@@ -53,6 +54,8 @@ __global__ __launch_bounds__(256, RS_WAVES_PER_EU) void ransac_kernel(RansacArgs
   __shared__ int s_cnt[RS_CH][M::MAXM];
   __shared__ double s_best[M::MS];
   __shared__ int s_ctl[8];  // 0: npass, 1: done, 2: maxGood, 3: iter, 4: niters, 5: consec_fail, 6: ok, 7: models scored
+  __shared__ int s_wpass[4];
+  __shared__ unsigned long long s_wmask[4];
   __shared__ unsigned long long s_rng;
 
   const int slot = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -95,9 +98,10 @@ __global__ __launch_bounds__(256, RS_WAVES_PER_EU) void ransac_kernel(RansacArgs
   }
 
   for (;;) {
-    // ---- 1. candidate samples, OpenCV's getSubset draw order ------------------------------------------
+    // ---- 1. candidate samples, OpenCV's getSubset draw order (sequential RNG stream, lane 0) ----------
     if (tid == 0) {
       GlRng rng(s_rng);
+      // never draw (much) more than can still be consumed: iterations left, with head-room for checkSubset rejects
       for (int a = 0; a < RS_CH; a++) {
         for (int i = 0; i < M::MP; ++i) {
           int idx_i;
@@ -113,79 +117,88 @@ __global__ __launch_bounds__(256, RS_WAVES_PER_EU) void ransac_kernel(RansacArgs
       s_rng = rng.state;
     }
     __syncthreads();
-    // ---- 2. checkSubset in parallel + ordered compaction --------------------------------------------------
-    if (wave == 0) {
-      float ms1[M::MP * M::PT1], ms2[M::MP * M::PT2];
+    // ---- 2. checkSubset in parallel (one candidate per lane) + ordered compaction over the 4 waves -------
+    float ms1[M::MP * M::PT1], ms2[M::MP * M::PT2];
+    bool pass = false;
+    if (tid < RS_CH) {
       for (int i = 0; i < M::MP; i++) {
-        int id = s_att[lane][i];
+        int id = s_att[tid][i];
         for (int k = 0; k < M::PT1; k++) ms1[i * M::PT1 + k] = m1[(size_t)id * M::PT1 + k];
         for (int k = 0; k < M::PT2; k++) ms2[i * M::PT2 + k] = m2[(size_t)id * M::PT2 + k];
       }
-      bool pass = M::check_subset(ms1, ms2);
-      unsigned long long bm = __ballot(pass);
-      int pos = __popcll(bm & ((1ull << lane) - 1));
-      if (pass)
-        for (int i = 0; i < M::MP; i++) s_idx[pos][i] = s_att[lane][i];
-      if (lane == 0) {
-        int np = __popcll(bm);
-        s_ctl[0] = np;
-        // OpenCV gives up on an iteration after 10000 consecutive failing attempts
-        int tail = bm ? __clzll(bm) : 64;  // failing attempts after the last pass
-        int run = s_ctl[5];
-        bool abort_ = false;
-        if (np == 0) { run += 64; abort_ = run >= 10000; }
-        else {
-          int lead = __ffsll((long long)bm) - 1;  // failing attempts before the first pass
-          abort_ = (run + lead) >= 10000;
-          run = tail;
-        }
-        s_ctl[5] = run;
-        if (abort_) s_ctl[1] = 1;
-      }
+      pass = M::check_subset(ms1, ms2);
     }
+    const unsigned long long bm = __ballot(pass);
+    if (lane == 0) { s_wpass[wave] = __popcll(bm); s_wmask[wave] = bm; }
     __syncthreads();
-    if (s_ctl[1]) break;
-    const int npass = s_ctl[0];
-    // ---- 3. minimal solver, one hypothesis per lane ---------------------------------------------------------
+    int pos = __popcll(bm & ((1ull << lane) - 1));
+    for (int w = 0; w < wave; w++) pos += s_wpass[w];
+    if (pass)
+      for (int i = 0; i < M::MP; i++) s_idx[pos][i] = s_att[tid][i];
+    if (tid == 0) {
+      // OpenCV gives up on an iteration after 10000 consecutive failing attempts: walk the pass bits in order
+      int np = 0, run = s_ctl[5];
+      bool abort_ = false;
+      for (int w = 0; w < RS_CH / 64; w++) {
+        unsigned long long m = s_wmask[w];
+        np += __popcll(m);
+        if (m == 0) { run += 64; abort_ |= run >= 10000; }
+        else {
+          int lead = __ffsll((long long)m) - 1;
+          abort_ |= (run + lead) >= 10000;
+          run = __clzll(m);
+        }
+      }
+      s_ctl[0] = np;
+      s_ctl[5] = run;
+      if (abort_) s_ctl[1] = 1;
+    }
     if (tid < RS_CH) {
       s_nmodels[tid] = 0;
       for (int k = 0; k < M::MAXM; k++) s_cnt[tid][k] = 0;
     }
     __syncthreads();
-    if (wave == 0 && lane < npass) {
-      float ms1[M::MP * M::PT1], ms2[M::MP * M::PT2];
+    if (s_ctl[1]) break;
+    const int npass = s_ctl[0];
+    // ---- 3. minimal solver, one hypothesis per lane; only as many as can still be consumed ---------------
+    const int nsolve = min(npass, s_ctl[4] - s_ctl[3]);
+    int nm = 0;
+    if (tid < nsolve) {
       for (int i = 0; i < M::MP; i++) {
-        int id = s_idx[lane][i];
+        int id = s_idx[tid][i];
         for (int k = 0; k < M::PT1; k++) ms1[i * M::PT1 + k] = m1[(size_t)id * M::PT1 + k];
         for (int k = 0; k < M::PT2; k++) ms2[i * M::PT2 + k] = m2[(size_t)id * M::PT2 + k];
       }
       double models[M::MAXM * M::MS];
-      int nm = M::solve(A.P, ms1, ms2, models);
+      nm = M::solve(A.P, ms1, ms2, models);
       if (nm < 0) nm = 0;
       if (nm > M::MAXM) nm = M::MAXM;
-      s_nmodels[lane] = nm;
+      s_nmodels[tid] = nm;
       for (int q = 0; q < nm; q++)
-        for (int k = 0; k < M::MS; k++) s_models[lane][q][k] = models[q * M::MS + k];
+        for (int k = 0; k < M::MS; k++) s_models[tid][q][k] = models[q * M::MS + k];
     }
     __syncthreads();
-    // ---- 4. scoring: hypothesis = lane, point quarter = wave ---------------------------------------------
-    if (lane < npass) {
-      int nm = s_nmodels[lane];
-      for (int q = 0; q < nm; q++) {
-        typename M::Scorer sc;
-        sc.init(A.P, &s_models[lane][q][0]);
-        int good = 0;
-        for (int i = wave; i < count; i += 4) good += sc.err(m1 + (size_t)i * M::PT1, m2 + (size_t)i * M::PT2) <= t;
-        atomicAdd(&s_cnt[lane][q], good);
+    // ---- 4. scoring: hypothesis = tid % RS_CH, point partition = tid / RS_CH; integer inlier counts ------------
+    {
+      const int hyp = tid % RS_CH, part = tid / RS_CH;
+      if (hyp < nsolve) {
+        const int nmh = s_nmodels[hyp];
+        for (int q = 0; q < nmh; q++) {
+          typename M::Scorer sc;
+          sc.init(A.P, &s_models[hyp][q][0]);
+          int good = 0;
+          for (int i = part; i < count; i += RS_PARTS) good += sc.err(m1 + (size_t)i * M::PT1, m2 + (size_t)i * M::PT2) <= t;
+          atomicAdd(&s_cnt[hyp][q], good);
+        }
       }
     }
     __syncthreads();
     // ---- 5. ordered replay of OpenCV's consensus update -------------------------------------------------------
     if (tid == 0) {
       int maxGood = s_ctl[2], iter = s_ctl[3], niters = s_ctl[4], scored = s_ctl[7];
-      for (int h = 0; h < npass && iter < niters; h++, iter++) {
-        int nm = s_nmodels[h];
-        for (int q = 0; q < nm; q++) {
+      for (int h = 0; h < nsolve && iter < niters; h++, iter++) {
+        int nmh = s_nmodels[h];
+        for (int q = 0; q < nmh; q++) {
           int good = s_cnt[h][q];
           scored++;
           if (good > max(maxGood, M::MP - 1)) {
@@ -247,19 +260,20 @@ __global__ __launch_bounds__(1024) void mask_to_indices_kernel(const u8* __restr
 }
 
 #define PR_T 256
-// deterministic block-wide sum of `K` doubles per thread (tree over LDS, fixed order)
+// deterministic block-wide sum of `K` doubles per thread: shuffle tree inside each wave, then the four wave
+// partials through LDS (2 barriers in total, fixed summation order).  s_red must hold 4*K doubles.
 template <int K>
-__device__ inline void block_sum(double* v, double* s_red /* [PR_T] */, double* out /* [K], valid in all threads */) {
+__device__ inline void block_sum(double* v, double* s_red, double* out /* [K], valid in all threads */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int k = 0; k < K; k++) {
-    s_red[threadIdx.x] = v[k];
-    __syncthreads();
-    for (int s = PR_T / 2; s > 0; s >>= 1) {
-      if (threadIdx.x < s) s_red[threadIdx.x] += s_red[threadIdx.x + s];
-      __syncthreads();
-    }
-    out[k] = s_red[0];
-    __syncthreads();
+    double x = v[k];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
+    if (lane == 0) s_red[wave * K + k] = x;
   }
+  __syncthreads();
+  for (int k = 0; k < K; k++) out[k] = ((s_red[k] + s_red[K + k]) + s_red[2 * K + k]) + s_red[3 * K + k];
+  __syncthreads();
 }
 
 struct PnpRefineArgs {
@@ -277,8 +291,9 @@ struct PnpRefineArgs {
 // One workgroup per stream.  Sums over the inlier set are block reductions in a fixed order (the oracle
 // sums sequentially, so R,t agree to rounding, not bit for bit); the small dense solves run on lane 0.
 __global__ __launch_bounds__(PR_T) void pnp_refine_kernel(PnpRefineArgs A) {
-  __shared__ double s_red[PR_T];
+  __shared__ double s_red[4 * 78];
   __shared__ double s_sh[160];  // broadcast area
+  __shared__ double s_mat[2 * 144 + 16];  // lane-0 dense solves work in LDS, not in scratch (latency)
   __shared__ int s_flag[4];
   const int slot = blockIdx.x, tid = threadIdx.x;
   int* result = A.result + (size_t)slot * 8;
@@ -389,7 +404,9 @@ __global__ __launch_bounds__(PR_T) void pnp_refine_kernel(PnpRefineArgs A) {
       bool okH = !degenerate;
       double h[9];
       if (okH) {
-        double L[81], W[9], V[81];
+        double* L = s_mat;
+        double* V = s_mat + 144;
+        double W[9];
         int q = 0;
         for (int j = 0; j < 9; j++)
           for (int k = j; k < 9; k++) { L[j * 9 + k] = LtL[q]; L[k * 9 + j] = LtL[q]; q++; }
@@ -454,7 +471,9 @@ __global__ __launch_bounds__(PR_T) void pnp_refine_kernel(PnpRefineArgs A) {
     }
     block_sum<78>(acc, s_red, LL);
     if (tid == 0) {
-      double L[144], LW[12], LV[144];
+      double* L = s_mat;
+      double* LV = s_mat + 144;
+      double* LW = s_mat + 288;
       int q = 0;
       for (int a = 0; a < 12; a++)
         for (int b = a; b < 12; b++) { L[a * 12 + b] = LL[q]; L[b * 12 + a] = LL[q]; q++; }
@@ -497,12 +516,13 @@ __global__ __launch_bounds__(PR_T) void pnp_refine_kernel(PnpRefineArgs A) {
     if (tid == 0) {
       const double LOG10 = log(10.);
       double lambda = exp(lambdaLg10 * LOG10);
-      double Am[36], x[6];
+      double* Am = s_mat;
+      double x[6];
       int q = 0;
       for (int a = 0; a < 6; a++)
         for (int b = a; b < 6; b++) { Am[a * 6 + b] = JtJ[q]; Am[b * 6 + a] = JtJ[q]; q++; }
       for (int i = 0; i < 6; i++) Am[i * 6 + i] *= 1. + lambda;
-      gl_solve_svd(Am, 6, 6, JtErr, x);
+      gl_solve_svd_ws(Am, 6, 6, JtErr, x, s_mat + 40, s_mat + 80);
       for (int i = 0; i < 6; i++) s_sh[i] = prevParam[i] - x[i];
     }
     __syncthreads();

@@ -313,6 +313,15 @@ __device__ GL_NOINLINE void gl_svbksb(int m, int n, const double* w, const doubl
   }
 }
 
+// cv::solve(A (m x n, m >= n <= 6), b, x, DECOMP_SVD) with caller-supplied workspaces (e.g. in LDS): at >= m*n, vt >= n*n
+__device__ inline void gl_solve_svd_ws(const double* A, int m, int n, const double* b, double* x, double* at, double* vt) {
+  double w[6], buf[1];
+  for (int i = 0; i < m; i++)
+    for (int j = 0; j < n; j++) at[j * m + i] = A[i * n + j];
+  gl_jacobi_svd(at, m, w, vt, m, n, n);
+  gl_svbksb(m, n, w, at, m, vt, n, b, 1, 1, x, 1, buf);
+}
+
 // cv::solve(A (m x n, m >= n <= 6), b, x, DECOMP_SVD)
 __device__ inline void gl_solve_svd(const double* A, int m, int n, const double* b, double* x) {
   double at[36], w[6], vt[36], buf[1];

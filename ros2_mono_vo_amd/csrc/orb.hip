@@ -3,9 +3,10 @@
 //
 // Device pipeline, every launch covering all slots of the batch:
 //   resize_exact_kernel   8-level pyramid, INTER_LINEAR_EXACT 8.8 x 8.8 fixed point (level l from l-1)
-//   fast_score_kernel     FAST-9/16 corner test + cornerScore, LDS tile with 3-px halo, 1 pixel / lane
-//   nms_rows_kernel<0/1>  3x3 strict NMS + edgeThreshold cull; one wavefront per image row, __ballot +
-//                         popcount give an ORDERED (row-major) compaction: pass 0 counts, pass 1 emits
+//   fast_nms_kernel       FAST-9/16 + cornerScore + strict 3x3 NMS fused per 64x16 tile: antipodal-pair reject,
+//                         ballot-compacted candidate list in LDS, full score for candidates only, dword stores
+//   nms_rows_kernel<0/1>  edgeThreshold cull + ORDERED (row-major) compaction of the non-zero map entries; one
+//                         wavefront per image row, 4 pixels per lane, __ballot + popcount: pass 0 counts, pass 1 emits
 //   scan_rows/scan_slots  exclusive scans (rows -> levels -> slots) so candidates of the whole batch are
 //                         one dense array
 //   harris_kernel         7x7 Harris response of every candidate (int sums, f32 response)
@@ -122,11 +123,16 @@ __global__ __launch_bounds__(256) void resize_exact_kernel(const u8* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------
-// FAST-9/16 score map
+// FAST-9/16 + 3x3 NMS, fused: the output map holds the score of NMS survivors and 0 elsewhere
 // ---------------------------------------------------------------------------------------------------
 #define FT_W 64
 #define FT_H 16
-#define FT_P (FT_W + 6 + 2)  // LDS pitch (bytes)
+#define FT_PW (FT_W + 8)   // pixel tile: 1 (NMS halo) + 3 (circle radius) on each side
+#define FT_PH (FT_H + 8)
+#define FT_P 76            // pixel tile pitch (bytes)
+#define FT_SW (FT_W + 2)   // score tile (NMS halo 1)
+#define FT_SH (FT_H + 2)
+#define FT_SP 68           // score tile pitch
 
 __device__ __forceinline__ bool has9(unsigned m) {
   unsigned m2 = m | (m << 16);
@@ -173,34 +179,85 @@ __device__ __forceinline__ int fast_score_px(const u8* c, int t) {
   return max(a0, -b0) - 1;
 }
 
-__global__ __launch_bounds__(256) void fast_score_kernel(const u8* __restrict__ pyr, u8* __restrict__ score,
-                                                         size_t slot_stride, size_t off, int w, int h, int pitch,
-                                                         int threshold) {
-  __shared__ u8 s[(FT_H + 6) * FT_P];
+// `lo`: scores are only needed for x in [lo, w-lo), y in [lo, h-lo) (lo = max(3, edge-1): NMS of the rows/cols the
+// compaction scans needs one ring of neighbours; everything else is written as 0).
+__global__ __launch_bounds__(256) void fast_nms_kernel(const u8* __restrict__ pyr, u8* __restrict__ score, size_t slot_stride, size_t off,
+                                                       int w, int h, int pitch, int threshold, int lo) {
+  __shared__ u8 s_px[FT_PH * FT_P];
+  __shared__ u8 s_sc[FT_SH * FT_SP];
+  __shared__ unsigned short s_list[FT_SH * FT_SW];
+  __shared__ int s_n;
   const u8* sp = pyr + (size_t)blockIdx.z * slot_stride + off;
   u8* dp = score + (size_t)blockIdx.z * slot_stride + off;
-  int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
-  for (int i = threadIdx.x; i < (FT_H + 6) * (FT_W + 6); i += 256) {
-    int ty = i / (FT_W + 6), tx = i - ty * (FT_W + 6);
-    int gx = min(max(x0 - 3 + tx, 0), w - 1), gy = min(max(y0 - 3 + ty, 0), h - 1);
-    s[ty * FT_P + tx] = sp[(size_t)gy * pitch + gx];
+  const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid == 0) s_n = 0;
+  // tiles that cannot contain a needed score: write zeros and leave
+  const bool dead = x0 + FT_W + 1 <= lo || x0 - 1 >= w - lo || y0 + FT_H + 1 <= lo || y0 - 1 >= h - lo;
+  if (dead) {
+    int row = tid >> 4, c4 = (tid & 15) * 4;
+    if (y0 + row < h && x0 + c4 < pitch) *(unsigned*)(dp + (size_t)(y0 + row) * pitch + x0 + c4) = 0u;
+    return;
+  }
+  for (int i = tid; i < FT_PH * FT_PW; i += 256) {
+    int ty = i / FT_PW, tx = i - ty * FT_PW;
+    int gx = min(max(x0 - 4 + tx, 0), w - 1), gy = min(max(y0 - 4 + ty, 0), h - 1);
+    s_px[ty * FT_P + tx] = sp[(size_t)gy * pitch + gx];
+  }
+  for (int i = tid; i < FT_SH * FT_SP / 4; i += 256) ((unsigned*)s_sc)[i] = 0u;
+  __syncthreads();
+  // ---- phase 1: antipodal-pair reject (a 9-arc contains one pixel of every antipodal pair) + compaction -----
+  for (int i0 = 0; i0 < FT_SH * FT_SW; i0 += 256) {
+    int i = i0 + tid;
+    bool cand = false;
+    if (i < FT_SH * FT_SW) {
+      int sy = i / FT_SW, sx = i - sy * FT_SW;
+      int gx = x0 - 1 + sx, gy = y0 - 1 + sy;
+      if (gx >= lo && gx < w - lo && gy >= lo && gy < h - lo) {
+        const u8* c = &s_px[(sy + 3) * FT_P + sx + 3];
+        int v = c[0], vb = v + threshold, vd = v - threshold;
+        int p0 = c[3 * FT_P], p8 = c[-3 * FT_P], p4 = c[3], p12 = c[-3];
+        bool br = ((p0 > vb) | (p8 > vb)) & ((p4 > vb) | (p12 > vb));
+        bool dk = ((p0 < vd) | (p8 < vd)) & ((p4 < vd) | (p12 < vd));
+        cand = br | dk;
+      }
+    }
+    unsigned long long m = __ballot(cand);
+    int base = 0;
+    if (lane == 0 && m) base = atomicAdd(&s_n, __popcll(m));
+    base = __shfl(base, 0, 64);
+    if (cand) s_list[base + __popcll(m & ((1ull << lane) - 1))] = (unsigned short)i;
   }
   __syncthreads();
-  int tx = threadIdx.x & 63;
+  // ---- phase 2: full 16-pixel test + cornerScore for the survivors only (dense lanes) ---------------------------
+  const int n = s_n;
+  for (int k = tid; k < n; k += 256) {
+    int i = s_list[k];
+    int sy = i / FT_SW, sx = i - sy * FT_SW;
+    int sc = fast_score_px(&s_px[(sy + 3) * FT_P + sx + 3], threshold);
+    s_sc[sy * FT_SP + sx] = (u8)sc;
+  }
+  __syncthreads();
+  // ---- phase 3: strict 3x3 NMS, 4 pixels per lane, one dword store -----------------------------------------------
+  {
+    int row = tid >> 4, c4 = (tid & 15) * 4;
+    const u8* r1 = &s_sc[(row + 1) * FT_SP + c4 + 1];
+    const u8* r0 = r1 - FT_SP;
+    const u8* r2 = r1 + FT_SP;
+    unsigned out = 0;
 #pragma unroll
-  for (int q = 0; q < 4; q++) {
-    int ty = (threadIdx.x >> 6) * 4 + q;
-    int x = x0 + tx, y = y0 + ty;
-    if (x < w && y < h) {
-      int sc = 0;
-      if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) sc = fast_score_px(&s[(ty + 3) * FT_P + tx + 3], threshold);
-      dp[(size_t)y * pitch + x] = (u8)sc;
+    for (int j = 0; j < 4; j++) {
+      int sv = r1[j];
+      bool keep = sv && sv > r1[j - 1] && sv > r1[j + 1] && sv > r0[j - 1] && sv > r0[j] && sv > r0[j + 1] && sv > r2[j - 1] &&
+                  sv > r2[j] && sv > r2[j + 1];
+      out |= keep ? ((unsigned)sv << (8 * j)) : 0u;
     }
+    if (y0 + row < h && x0 + c4 < pitch) *(unsigned*)(dp + (size_t)(y0 + row) * pitch + x0 + c4) = out;
   }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// NMS + ordered compaction
+// ordered compaction of the non-zero entries of the NMS map (row-major), 4 pixels per lane
 // ---------------------------------------------------------------------------------------------------
 template <int EMIT>
 __global__ __launch_bounds__(256) void nms_rows_kernel(const u8* __restrict__ score, OrbGeom G, int* __restrict__ row_cnt,
@@ -219,30 +276,36 @@ __global__ __launch_bounds__(256) void nms_rows_kernel(const u8* __restrict__ sc
   const int w = G.w[l], pitch = G.pitch[l];
   const int y = G.edge + (row - G.row0[l]);
   const u8* sp = score + (size_t)slot * G.slot_stride + G.off[l] + (size_t)y * pitch;
+  const int xlo = G.edge, xhi = w - G.edge;  // [xlo, xhi)
   int count = 0;
   int base = 0;
   if (EMIT) base = slot_base[slot] + row_off[(size_t)slot * max_rows + row];
-  for (int xb = G.edge; xb < w - G.edge; xb += 64) {
-    int x = xb + lane;
-    bool keep = false;
-    int s = 0;
-    if (x < w - G.edge) {
-      s = sp[x];
-      if (s) {
-        const u8* u = sp - pitch;
-        const u8* d = sp + pitch;
-        keep = s > sp[x - 1] && s > sp[x + 1] && s > u[x - 1] && s > u[x] && s > u[x + 1] && s > d[x - 1] &&
-               s > d[x] && s > d[x + 1];
-      }
-    }
-    unsigned long long m = __ballot(keep);
-    if (EMIT && keep) {
-      int o = base + count + __popcll(m & ((1ull << lane) - 1));
+  for (int xb = xlo & ~3; xb < xhi; xb += 256) {
+    int x = xb + lane * 4;
+    unsigned v = 0;
+    if (x < xhi) v = *(const unsigned*)(sp + x);
+    // mask bytes outside [xlo, xhi)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (x + j < xlo || x + j >= xhi) v &= ~(0xFFu << (8 * j));
+    // NMS survivors are never horizontally adjacent, so a dword holds at most 2 of them
+    int j0 = -1, j1 = -1;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if ((v >> (8 * j)) & 0xFF) { if (j0 < 0) j0 = j; else j1 = j; }
+    unsigned long long m0 = __ballot(j0 >= 0), m1 = __ballot(j1 >= 0);
+    if (EMIT && j0 >= 0) {
+      unsigned long long below = (1ull << lane) - 1;
+      int o = base + count + __popcll(m0 & below) + __popcll(m1 & below);
       if (o < cand_cap) {
-        cx[o] = (unsigned short)x; cy[o] = (unsigned short)y; cs[o] = (u8)s; cl[o] = (u8)l; cslot[o] = slot;
+        cx[o] = (unsigned short)(x + j0); cy[o] = (unsigned short)y; cs[o] = (u8)((v >> (8 * j0)) & 0xFF); cl[o] = (u8)l; cslot[o] = slot;
+      }
+      if (j1 >= 0 && o + 1 < cand_cap) {
+        cx[o + 1] = (unsigned short)(x + j1); cy[o + 1] = (unsigned short)y; cs[o + 1] = (u8)((v >> (8 * j1)) & 0xFF); cl[o + 1] = (u8)l;
+        cslot[o + 1] = slot;
       }
     }
-    count += __popcll(m);
+    count += __popcll(m0) + __popcll(m1);
   }
   if (!EMIT && lane == 0) row_cnt[(size_t)slot * max_rows + row] = count;
 }
@@ -587,8 +650,8 @@ static int orb_detect_device(mvo_ctx* ctx, const OrbGeom& G, int nslots) {
   }
   for (int l = 0; l < G.nlevels; l++) {
     dim3 grid((G.w[l] + FT_W - 1) / FT_W, (G.h[l] + FT_H - 1) / FT_H, nslots);
-    hipLaunchKernelGGL(fast_score_kernel, grid, dim3(256), 0, st, o->d_pyr, o->d_score, G.slot_stride, G.off[l], G.w[l],
-                       G.h[l], G.pitch[l], ctx->cfg.fast_threshold);
+    hipLaunchKernelGGL(fast_nms_kernel, grid, dim3(256), 0, st, o->d_pyr, o->d_score, G.slot_stride, G.off[l], G.w[l],
+                       G.h[l], G.pitch[l], ctx->cfg.fast_threshold, std::max(3, G.edge - 1));
   }
   int nrows = G.row0[G.nlevels];
   if (nrows > 0) {
@@ -753,8 +816,8 @@ extern "C" int mvo_fast9_nms(mvo_ctx* ctx, const uint8_t* img, int w, int h, int
   G.row0[1] = (h <= 6 || w <= 6) ? 0 : h - 6;
   for (int l = 2; l <= MVO_ORB_LEVELS; l++) G.row0[l] = G.row0[1];
   dim3 grid((w + FT_W - 1) / FT_W, (h + FT_H - 1) / FT_H, 1);
-  hipLaunchKernelGGL(fast_score_kernel, grid, dim3(256), 0, st, o->d_pyr, o->d_score, G.slot_stride, G.off[0], w, h, G.pitch[0],
-                     threshold);
+  hipLaunchKernelGGL(fast_nms_kernel, grid, dim3(256), 0, st, o->d_pyr, o->d_score, G.slot_stride, G.off[0], w, h, G.pitch[0],
+                     threshold, 3);
   int nrows = G.row0[1];
   dim3 g2((nrows + 3) / 4, 1);
   hipLaunchKernelGGL(nms_rows_kernel<0>, g2, dim3(256), 0, st, o->d_score, G, o->d_row_cnt, o->d_row_off, o->d_slot_base,
