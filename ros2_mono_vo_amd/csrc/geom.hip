@@ -980,8 +980,25 @@ extern "C" int mvo_recover_pose(mvo_ctx* ctx, const double E[9], const float* p1
   return MVO_OK;
 }
 
-extern "C" int mvo_find_essential_ransac(mvo_ctx* ctx, const float*, const float*, int, const double*, double, double, int, uint8_t*,
-                                         double*, int*) {
-  if (ctx) ctx->set_error("mvo_find_essential_ransac: 5-point solver not built yet");
-  return MVO_E_ARG;
+extern "C" int mvo_find_essential_ransac(mvo_ctx* ctx, const float* p1, const float* p2, int n, const double K[9], double prob,
+                                         double thr, int max_iters, uint8_t* mask, double E[9], int* n_inliers) {
+  if (!ctx || !p1 || !p2 || !K || !mask || n < 0) return MVO_E_ARG;
+  if (n_inliers) *n_inliers = 0;
+  if (n < 5) { ctx->set_error("findEssentialMat needs at least 5 correspondences"); return MVO_E_ARG; }
+  GeomState* g = ctx->geom;
+  int rc = upload_pairs(ctx, p1, 2, p2, 2, n);
+  if (rc) return rc;
+  ModelParams P{};
+  P.cam = CamK{K[0], K[4], K[2], K[5]};
+  double thr_n = thr / ((K[0] + K[4]) / 2);  // findEssentialMat: threshold /= (fx + fy) / 2
+  launch_ransac<EModel>(ctx, ctx->stream, 1, g->d_m1, g->d_m2, ctx->maxpts * 2, ctx->maxpts * 2, g->d_n, thr_n, prob, max_iters, P,
+                        g->d_mask, ctx->maxpts, g->d_model, g->d_result);
+  MVO_HIP(hipMemcpyAsync(mask, g->d_mask, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  MVO_HIP(hipMemcpyAsync(g->h_model, g->d_model, 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MVO_HIP(hipMemcpyAsync(g->h_result, g->d_result, 8 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  MVO_HIP(hipStreamSynchronize(ctx->stream));
+  if (n_inliers) *n_inliers = g->h_result[0] ? g->h_result[1] : 0;
+  if (!g->h_result[0]) return MVO_E_DEGENERATE;
+  if (E) memcpy(E, g->h_model, 9 * sizeof(double));
+  return MVO_OK;
 }

@@ -628,3 +628,250 @@ struct PnPModel {
     }
   };
 };
+
+// ---------------------------------------------------------------------------------------------------
+// Essential matrix, 5 points (five-point.cpp EMEstimatorCallback) — Nister's solver.
+// Points are pixel floats; each use normalises them with K in double exactly like findEssentialMat
+// ((double)p - c) / f.  The 10x20 constraint matrix and det B(z) are expanded symbolically (same
+// arithmetic as oracle/orc_essential.cpp); roots by Durand-Kerner as cv::solvePoly.
+// ---------------------------------------------------------------------------------------------------
+struct EmPoly { double c[20]; };
+
+__device__ __constant__ signed char kEmMono[20][3] = {{3, 0, 0}, {0, 3, 0}, {2, 1, 0}, {1, 2, 0}, {2, 0, 1}, {2, 0, 0}, {0, 2, 1}, {0, 2, 0}, {1, 1, 1}, {1, 1, 0},
+                                                      {1, 0, 2}, {1, 0, 1}, {1, 0, 0}, {0, 1, 2}, {0, 1, 1}, {0, 1, 0}, {0, 0, 3}, {0, 0, 2}, {0, 0, 1}, {0, 0, 0}};
+
+__device__ GL_NOINLINE int em_mono_index(int a, int b, int c) {
+  for (int i = 0; i < 20; i++)
+    if (kEmMono[i][0] == a && kEmMono[i][1] == b && kEmMono[i][2] == c) return i;
+  return -1;
+}
+__device__ GL_NOINLINE void em_pmul(const EmPoly& a, const EmPoly& b, EmPoly& r) {
+  double out[20];
+  for (int i = 0; i < 20; i++) out[i] = 0;
+  for (int i = 0; i < 20; i++) {
+    if (a.c[i] == 0) continue;
+    for (int j = 0; j < 20; j++) {
+      if (b.c[j] == 0) continue;
+      int e0 = kEmMono[i][0] + kEmMono[j][0], e1 = kEmMono[i][1] + kEmMono[j][1], e2 = kEmMono[i][2] + kEmMono[j][2];
+      if (e0 + e1 + e2 > 3) continue;
+      out[em_mono_index(e0, e1, e2)] += a.c[i] * b.c[j];
+    }
+  }
+  for (int i = 0; i < 20; i++) r.c[i] = out[i];
+}
+__device__ __forceinline__ void em_padd(const EmPoly& a, const EmPoly& b, EmPoly& r) { for (int i = 0; i < 20; i++) r.c[i] = a.c[i] + b.c[i]; }
+__device__ __forceinline__ void em_psub(const EmPoly& a, const EmPoly& b, EmPoly& r) { for (int i = 0; i < 20; i++) r.c[i] = a.c[i] - b.c[i]; }
+
+// hal::LU64f with right-hand side (partial pivoting); m = n = 10 here
+__device__ GL_NOINLINE int em_lu_solve(double* A, int m, double* b, int n) {
+  const double eps = DBL_EPSILON * 100;
+  int i, j, k, p = 1;
+  for (i = 0; i < m; i++) {
+    k = i;
+    for (j = i + 1; j < m; j++)
+      if (fabs(A[j * m + i]) > fabs(A[k * m + i])) k = j;
+    if (fabs(A[k * m + i]) < eps) return 0;
+    if (k != i) {
+      for (j = i; j < m; j++) gl_swap(A[i * m + j], A[k * m + j]);
+      for (j = 0; j < n; j++) gl_swap(b[i * n + j], b[k * n + j]);
+      p = -p;
+    }
+    double d = -1 / A[i * m + i];
+    for (j = i + 1; j < m; j++) {
+      double alpha = A[j * m + i] * d;
+      for (k = i + 1; k < m; k++) A[j * m + k] += alpha * A[i * m + k];
+      for (k = 0; k < n; k++) b[j * n + k] += alpha * b[i * n + k];
+    }
+  }
+  for (i = m - 1; i >= 0; i--)
+    for (j = 0; j < n; j++) {
+      double s = b[i * n + j];
+      for (k = i + 1; k < m; k++) s -= A[i * m + k] * b[k * n + j];
+      b[i * n + j] = s / A[i * m + i];
+    }
+  return p;
+}
+
+// cv::solvePoly (Durand-Kerner), ascending coefficients, degree n0 = 10
+__device__ GL_NOINLINE int em_solve_poly(const double* c, int n0, double* re, double* im) {
+  int n = n0;
+  for (; n > 1; n--)
+    if (fabs(c[n]) > DBL_EPSILON) break;
+  double pr = 1, pi = 0;
+  for (int i = 0; i < n; i++) {
+    re[i] = pr; im[i] = pi;
+    double t = pr * 1 - pi * 1;
+    pi = pr * 1 + pi * 1;
+    pr = t;
+  }
+  for (int iter = 0; iter < 1000; iter++) {
+    double maxDiff = 0;
+    for (int i = 0; i < n; i++) {
+      double p_re = re[i], p_im = im[i];
+      double num_re = c[n], num_im = 0, den_re = c[n], den_im = 0;
+      for (int j = 0; j < n; j++) {
+        double t = num_re * p_re - num_im * p_im;
+        num_im = num_re * p_im + num_im * p_re;
+        num_re = t + c[n - j - 1];
+        if (j != i) {
+          double d_re = p_re - re[j], d_im = p_im - im[j];
+          if (d_re != 0 || d_im != 0) {
+            double t2 = den_re * d_re - den_im * d_im;
+            den_im = den_re * d_im + den_im * d_re;
+            den_re = t2;
+          }
+        }
+      }
+      double tt = 1. / (den_re * den_re + den_im * den_im);
+      double q_re = (num_re * den_re + num_im * den_im) * tt;
+      double q_im = (-num_re * den_im + num_im * den_re) * tt;
+      re[i] = p_re - q_re; im[i] = p_im - q_im;
+      maxDiff = fmax(maxDiff, sqrt(q_re * q_re + q_im * q_im));
+    }
+    if (maxDiff <= 0) break;
+  }
+  for (int i = 0; i < n; i++)
+    if (fabs(im[i]) < 1e-100) im[i] = 0;
+  for (int k = n; k < n0; k++) { re[k] = re[k - 1]; im[k] = im[k - 1]; }
+  return n;
+}
+
+__device__ GL_NOINLINE int em_solve5(const double* q1, const double* q2, double* models) {
+  const int n = 5;
+  double Q[45];
+  for (int i = 0; i < n; i++) {
+    double x1 = q1[2 * i], y1 = q1[2 * i + 1], x2 = q2[2 * i], y2 = q2[2 * i + 1];
+    double* q = &Q[i * 9];
+    q[0] = x2 * x1; q[1] = x2 * y1; q[2] = x2; q[3] = y2 * x1; q[4] = y2 * y1; q[5] = y2; q[6] = x1; q[7] = y1; q[8] = 1.0;
+  }
+  double w[9], Vt[81], ta[81], tv[25];
+  gl_svd_compute(Q, n, 9, w, nullptr, Vt, true, ta, tv);
+  const double* EE[4] = {Vt + 45, Vt + 54, Vt + 63, Vt + 72};
+  EmPoly E[9];
+  for (int k = 0; k < 9; k++) {
+    for (int i = 0; i < 20; i++) E[k].c[i] = 0;
+    E[k].c[12] = EE[0][k]; E[k].c[15] = EE[1][k]; E[k].c[18] = EE[2][k]; E[k].c[19] = EE[3][k];  // x, y, z, 1
+  }
+  EmPoly rows[10], t1, t2, t3;
+  // det(E) = E0 (E4 E8 - E5 E7) - E1 (E3 E8 - E5 E6) + E2 (E3 E7 - E4 E6)
+  em_pmul(E[4], E[8], t1); em_pmul(E[5], E[7], t2); em_psub(t1, t2, t1); em_pmul(E[0], t1, rows[0]);
+  em_pmul(E[3], E[8], t1); em_pmul(E[5], E[6], t2); em_psub(t1, t2, t1); em_pmul(E[1], t1, t3); em_psub(rows[0], t3, rows[0]);
+  em_pmul(E[3], E[7], t1); em_pmul(E[4], E[6], t2); em_psub(t1, t2, t1); em_pmul(E[2], t1, t3); em_padd(rows[0], t3, rows[0]);
+  EmPoly EEt[9], tr;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      em_pmul(E[i * 3], E[j * 3], t1); em_pmul(E[i * 3 + 1], E[j * 3 + 1], t2); em_padd(t1, t2, t1);
+      em_pmul(E[i * 3 + 2], E[j * 3 + 2], t2); em_padd(t1, t2, EEt[i * 3 + j]);
+    }
+  em_padd(EEt[0], EEt[4], tr); em_padd(tr, EEt[8], tr);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      em_pmul(EEt[i * 3], E[j], t1); em_pmul(EEt[i * 3 + 1], E[3 + j], t2); em_padd(t1, t2, t1);
+      em_pmul(EEt[i * 3 + 2], E[6 + j], t2); em_padd(t1, t2, t1);
+      for (int k = 0; k < 20; k++) t1.c[k] = t1.c[k] * 2.0;
+      em_pmul(tr, E[i * 3 + j], t2);
+      em_psub(t1, t2, rows[1 + i * 3 + j]);
+    }
+  double A1[100], A2[100];
+  for (int r = 0; r < 10; r++)
+    for (int c = 0; c < 10; c++) { A1[r * 10 + c] = rows[r].c[c]; A2[r * 10 + c] = rows[r].c[10 + c]; }
+  if (!em_lu_solve(A1, 10, A2, 10)) return 0;
+  const double* A = A2;
+  double b[39];
+  for (int i = 0; i < 3; i++) {
+    const double* a1 = A + (i * 2 + 4) * 10;
+    const double* a2 = A + (i * 2 + 5) * 10;
+    double row1[13], row2[13];
+    for (int k = 0; k < 13; k++) { row1[k] = 0; row2[k] = 0; }
+    for (int k = 0; k < 3; k++) { row1[1 + k] = a1[k]; row1[5 + k] = a1[3 + k]; row2[k] = a2[k]; row2[4 + k] = a2[3 + k]; }
+    for (int k = 0; k < 4; k++) { row1[9 + k] = a1[6 + k]; row2[8 + k] = a2[6 + k]; }
+    for (int k = 0; k < 13; k++) b[i * 13 + k] = row1[k] - row2[k];
+  }
+  double P[3][3][5];
+  const int deg[3] = {4, 4, 5};
+  for (int j = 0; j < 3; j++) {
+    const double* br = b + j * 13;
+    for (int k = 0; k < 4; k++) { P[j][0][k] = br[3 - k]; P[j][1][k] = br[7 - k]; }
+    P[j][0][4] = P[j][1][4] = 0;
+    for (int k = 0; k < 5; k++) P[j][2][k] = br[12 - k];
+  }
+  double c[11];
+  for (int k = 0; k < 11; k++) c[k] = 0;
+  const int perm[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {1, 0, 2}, {2, 1, 0}};
+  const double sgn[6] = {1, 1, 1, -1, -1, -1};
+  for (int q = 0; q < 6; q++) {
+    double u1[9], u2[13];
+    const double* pa = P[0][perm[q][0]]; int na = deg[perm[q][0]];
+    const double* pb = P[1][perm[q][1]]; int nb = deg[perm[q][1]];
+    const double* pc = P[2][perm[q][2]]; int nc = deg[perm[q][2]];
+    for (int i = 0; i < na + nb - 1; i++) u1[i] = 0;
+    for (int i = 0; i < na; i++)
+      for (int j = 0; j < nb; j++) u1[i + j] += pa[i] * pb[j];
+    int n1 = na + nb - 1;
+    for (int i = 0; i < n1 + nc - 1; i++) u2[i] = 0;
+    for (int i = 0; i < n1; i++)
+      for (int j = 0; j < nc; j++) u2[i + j] += u1[i] * pc[j];
+    for (int k = 0; k < 11; k++) c[k] += sgn[q] * u2[k];
+  }
+  double rre[16], rim[16];
+  em_solve_poly(c, 10, rre, rim);
+  int count = 0;
+  for (int i = 0; i < 10; i++) {
+    if (fabs(rim[i]) > 1e-10) continue;
+    double z1 = rre[i], z2 = z1 * z1, z3 = z2 * z1, z4 = z3 * z1;
+    double bz[9];
+    for (int j = 0; j < 3; j++) {
+      const double* br = b + j * 13;
+      bz[j * 3] = br[0] * z3 + br[1] * z2 + br[2] * z1 + br[3];
+      bz[j * 3 + 1] = br[4] * z3 + br[5] * z2 + br[6] * z1 + br[7];
+      bz[j * 3 + 2] = br[8] * z4 + br[9] * z3 + br[10] * z2 + br[11] * z1 + br[12];
+    }
+    double ww[3], vt[9];
+    gl_svd3(bz, ww, nullptr, vt);
+    const double* xy1 = vt + 6;
+    if (fabs(xy1[2]) < 1e-10) continue;
+    double xs = xy1[0] / xy1[2], ys = xy1[1] / xy1[2], zs = z1;
+    double Ev[9], nrm = 0;
+    for (int k = 0; k < 9; k++) {
+      Ev[k] = EE[0][k] * xs + EE[1][k] * ys + EE[2][k] * zs + EE[3][k];
+      nrm += Ev[k] * Ev[k];
+    }
+    nrm = sqrt(nrm);
+    for (int k = 0; k < 9; k++) models[count * 9 + k] = Ev[k] / nrm;
+    count++;
+  }
+  return count;
+}
+
+struct EModel {
+  static constexpr int MP = 5, MAXM = 10, MS = 9, PT1 = 2, PT2 = 2;
+  __device__ static bool check_subset(const float*, const float*) { return true; }
+  __device__ static int solve(const ModelParams& P, const float* ms1, const float* ms2, double* models) {
+    double q1[10], q2[10];
+    for (int i = 0; i < 5; i++) {
+      q1[2 * i] = ((double)ms1[2 * i] - P.cam.cx) / P.cam.fx; q1[2 * i + 1] = ((double)ms1[2 * i + 1] - P.cam.cy) / P.cam.fy;
+      q2[2 * i] = ((double)ms2[2 * i] - P.cam.cx) / P.cam.fx; q2[2 * i + 1] = ((double)ms2[2 * i + 1] - P.cam.cy) / P.cam.fy;
+    }
+    return em_solve5(q1, q2, models);
+  }
+  struct Scorer {
+    double E[9];
+    CamK cam;
+    __device__ void init(const ModelParams& P, const double* e) {
+      for (int i = 0; i < 9; i++) E[i] = e[i];
+      cam = P.cam;
+    }
+    __device__ __forceinline__ float err(const float* p1, const float* p2) const {
+      double x1[3] = {((double)p1[0] - cam.cx) / cam.fx, ((double)p1[1] - cam.cy) / cam.fy, 1.};
+      double x2[3] = {((double)p2[0] - cam.cx) / cam.fx, ((double)p2[1] - cam.cy) / cam.fy, 1.};
+      double Ex1[3], Etx2[3];
+      for (int r = 0; r < 3; r++) {
+        Ex1[r] = E[r * 3] * x1[0] + E[r * 3 + 1] * x1[1] + E[r * 3 + 2] * x1[2];
+        Etx2[r] = E[r] * x2[0] + E[3 + r] * x2[1] + E[6 + r] * x2[2];
+      }
+      double x2tEx1 = x2[0] * Ex1[0] + x2[1] * Ex1[1] + x2[2] * Ex1[2];
+      double a = Ex1[0] * Ex1[0], b = Ex1[1] * Ex1[1], c = Etx2[0] * Etx2[0], d = Etx2[1] * Etx2[1];
+      return (float)(x2tEx1 * x2tEx1 / (a + b + c + d));
+    }
+  };
+};

@@ -153,17 +153,19 @@ def render_planes(w: int, h: int, K: np.ndarray, R_cw: np.ndarray, t_cw: np.ndar
     return np.clip(np.rint(img), 0, 255).astype(np.uint8), depth
 
 
-def make_plane_scene(seed: int = 7):
-    """A background wall + a few nearer billboards: genuine parallax for the Initializer."""
+def make_plane_scene(seed: int = 7, scale: float = 1.0):
+    """A background wall + a few nearer billboards: genuine parallax for the Initializer.  `scale` shrinks the
+    whole scene (depths 30 / 8-20 m at scale 1)."""
     planes = []
     tex = base_texture(2048, 1536, seed, margin=0)
-    planes.append(dict(z=30.0, x0=-60.0, x1=60.0, y0=-40.0, y1=40.0, tex=tex, ppm=tex.shape[1] / 120.0))
+    planes.append(dict(z=30.0 * scale, x0=-60.0 * scale, x1=60.0 * scale, y0=-40.0 * scale, y1=40.0 * scale, tex=tex,
+                       ppm=tex.shape[1] / (120.0 * scale)))
     rng = np.random.default_rng(seed + 1)
     for i in range(6):
-        z = float(rng.uniform(8.0, 20.0))
-        cx = float(rng.uniform(-8, 8))
-        cy = float(rng.uniform(-5, 5))
-        sw, sh = float(rng.uniform(3, 6)), float(rng.uniform(2, 4))
+        z = float(rng.uniform(8.0, 20.0)) * scale
+        cx = float(rng.uniform(-8, 8)) * scale
+        cy = float(rng.uniform(-5, 5)) * scale
+        sw, sh = float(rng.uniform(3, 6)) * scale, float(rng.uniform(2, 4)) * scale
         t = base_texture(640, 480, seed + 10 + i, margin=0)
         planes.append(dict(z=z, x0=cx - sw, x1=cx + sw, y0=cy - sh, y1=cy + sh, tex=t, ppm=t.shape[1] / (2 * sw)))
     return planes
