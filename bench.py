@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="independent camera streams per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="independent camera streams per GPU")
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--nfeatures", type=int, default=2000)
@@ -144,6 +144,14 @@ def main():
         lk = prof.get("lk_track", {"ms_avg": 0, "launches": 0})
         algo_bytes = ALGO_BYTES_PER_LK_POINT * (lk_points / max(K, 1))
         achieved = algo_bytes / (lk["ms_avg"] * 1e-3) / 1e9 if lk["ms_avg"] else 0.0
+        # HBM traffic of the kernel from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes;
+        # profiles/r01_lk_pmc.json holds the measured bytes per tracked point), scaled to this launch's point count.
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_lk_pmc.json")))
+            traffic = int((pmc["fetch_bytes_per_point"] + pmc["write_bytes_per_point"]) * (lk_points / max(K, 1)))
+        except Exception:
+            pass
         line = {
             "metric": "tracker-step frames/sec @1280x720, 2000 ORB feats",
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
@@ -164,7 +172,7 @@ def main():
                        "mean_triangulated": float(np.mean([r.n_triangulated for r in last]))},
             "roofline": {"bound": "hbm", "kernel": "lk_track_kernel", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": None,
+                         "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": lk["ms_avg"]},
             "stage_ms": prof,
         }
