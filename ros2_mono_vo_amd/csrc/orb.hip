@@ -13,7 +13,7 @@
 //   [host]                KeyPointsFilter::retainBest twice per level with libstdc++ nth_element/partition
 //                         on the response arrays only: that permutation IS OpenCV's key-point order
 //   ic_angle_kernel       intensity-centroid orientation, one wavefront per key-point, exact int moments
-//   blur7_kernel          7x7 Gaussian in the 8-bit fixed point ORB gets (LDS separable)
+//   blur7_kernel          7x7 Gaussian in the 8-bit fixed point ORB gets: v_dot4_u32_u8 rows, v_dot2_u32_u16 columns
 //   brief_kernel          rotated BRIEF, 32 lanes per key-point (one descriptor byte per lane)
 #include "mvo_internal.h"
 
@@ -473,36 +473,79 @@ __global__ __launch_bounds__(256) void ic_angle_kernel(const u8* __restrict__ py
 // ---------------------------------------------------------------------------------------------------
 #define BL_W 64
 #define BL_H 16
+#define BL_SP 72   // source tile pitch: 64 + 3 + 3 columns, 4-byte aligned origin at x0 - 4
+#define BL_HP 26   // transposed row-sum pitch in u16 (22 rows + pad; 13 dwords: odd, so column reads spread over banks)
 struct BlurTaps { int k[7]; };
+typedef unsigned short bl_ushort2 __attribute__((ext_vector_type(2)));
 
+// Separable 7-tap blur, all-integer: horizontal taps by v_alignbyte + 2 x v_dot4_u32_u8 per pixel (4 pixels per lane),
+// row sums (<= 257*255, fit u16) stored transposed in LDS, vertical taps by 4 x v_dot2_u32_u16, (s + 2^15) >> 16.
 __global__ __launch_bounds__(256) void blur7_kernel(const u8* __restrict__ pyr, u8* __restrict__ out, size_t slot_stride,
                                                     size_t off, int w, int h, int pitch, BlurTaps T) {
-  __shared__ u8 s[(BL_H + 6)][BL_W + 8];
-  __shared__ unsigned short sh[(BL_H + 6)][BL_W];
+  __shared__ unsigned s_src[(BL_H + 6) * BL_SP / 4];
+  __shared__ unsigned short s_h[BL_W * BL_HP];
   const u8* sp = pyr + (size_t)blockIdx.z * slot_stride + off;
   u8* dp = out + (size_t)blockIdx.z * slot_stride + off;
-  int x0 = blockIdx.x * BL_W, y0 = blockIdx.y * BL_H;
-  for (int i = threadIdx.x; i < (BL_H + 6) * (BL_W + 6); i += 256) {
-    int ty = i / (BL_W + 6), tx = i - ty * (BL_W + 6);
-    int gx = d_reflect101(x0 - 3 + tx, w), gy = d_reflect101(y0 - 3 + ty, h);
-    s[ty][tx] = sp[(size_t)gy * pitch + gx];
+  const int x0 = blockIdx.x * BL_W, y0 = blockIdx.y * BL_H;
+  const int tid = threadIdx.x;
+  // ---- stage 1: source tile rows y0-3 .. y0+18, bytes x0-4 .. x0+67 ---------------------------------------
+  const bool interior = x0 >= 4 && x0 + 68 <= w && y0 >= 3 && y0 + BL_H + 3 <= h;
+  if (interior) {
+    for (int i = tid; i < (BL_H + 6) * (BL_SP / 4); i += 256) {
+      int ty = i / (BL_SP / 4), k = i - ty * (BL_SP / 4);
+      s_src[i] = *(const unsigned*)(sp + (size_t)(y0 - 3 + ty) * pitch + x0 - 4 + 4 * k);
+    }
+  } else {
+    u8* sb = (u8*)s_src;
+    for (int i = tid; i < (BL_H + 6) * BL_SP; i += 256) {
+      int ty = i / BL_SP, tx = i - ty * BL_SP;
+      int gx = d_reflect101(x0 - 4 + tx, w), gy = d_reflect101(y0 - 3 + ty, h);
+      sb[i] = sp[(size_t)gy * pitch + gx];
+    }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < (BL_H + 6) * BL_W; i += 256) {
-    int ty = i / BL_W, tx = i - ty * BL_W;
-    const u8* r = &s[ty][tx];
-    int v = T.k[0] * r[0] + T.k[1] * r[1] + T.k[2] * r[2] + T.k[3] * r[3] + T.k[4] * r[4] + T.k[5] * r[5] + T.k[6] * r[6];
-    sh[ty][tx] = (unsigned short)v;  // <= 257*255 = 65535
+  // ---- stage 2: horizontal pass, 4 outputs per work item ------------------------------------------------------------
+  const unsigned K0 = (unsigned)T.k[0] | ((unsigned)T.k[1] << 8) | ((unsigned)T.k[2] << 16) | ((unsigned)T.k[3] << 24);
+  const unsigned K1 = (unsigned)T.k[4] | ((unsigned)T.k[5] << 8) | ((unsigned)T.k[6] << 16);
+  for (int i = tid; i < (BL_H + 6) * 16; i += 256) {
+    int ty = i >> 4, c = i & 15;
+    const unsigned* r = &s_src[ty * (BL_SP / 4) + c];
+    unsigned d0 = r[0], d1 = r[1], d2 = r[2];  // bytes 4c .. 4c+11 of the tile row; output j uses bytes 4c+1+j .. 4c+7+j
+    unsigned lo0 = __builtin_amdgcn_alignbyte(d1, d0, 1), hi0 = __builtin_amdgcn_alignbyte(d2, d1, 1);
+    unsigned lo1 = __builtin_amdgcn_alignbyte(d1, d0, 2), hi1 = __builtin_amdgcn_alignbyte(d2, d1, 2);
+    unsigned lo2 = __builtin_amdgcn_alignbyte(d1, d0, 3), hi2 = __builtin_amdgcn_alignbyte(d2, d1, 3);
+    unsigned v0 = __builtin_amdgcn_udot4(lo0, K0, __builtin_amdgcn_udot4(hi0, K1, 0u, false), false);
+    unsigned v1 = __builtin_amdgcn_udot4(lo1, K0, __builtin_amdgcn_udot4(hi1, K1, 0u, false), false);
+    unsigned v2 = __builtin_amdgcn_udot4(lo2, K0, __builtin_amdgcn_udot4(hi2, K1, 0u, false), false);
+    unsigned v3 = __builtin_amdgcn_udot4(d1, K0, __builtin_amdgcn_udot4(d2, K1, 0u, false), false);
+    unsigned short* hcol = &s_h[(4 * c) * BL_HP + ty];
+    hcol[0] = (unsigned short)v0; hcol[BL_HP] = (unsigned short)v1; hcol[2 * BL_HP] = (unsigned short)v2; hcol[3 * BL_HP] = (unsigned short)v3;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < BL_H * BL_W; i += 256) {
-    int ty = i / BL_W, tx = i - ty * BL_W;
-    int x = x0 + tx, y = y0 + ty;
-    if (x < w && y < h) {
-      int v = 0;
+  // ---- stage 3: vertical pass, lane = column, 4 output rows per lane ------------------------------------------------
+  {
+    const int x = tid & 63, r0 = (tid >> 6) * 4;
+    const unsigned* hc = (const unsigned*)&s_h[x * BL_HP + r0];  // rows r0 .. r0+9 (r0 % 4 == 0 -> dword aligned)
+    unsigned e0 = hc[0], e1 = hc[1], e2 = hc[2], e3 = hc[3], e4 = hc[4];
+    const unsigned T01 = (unsigned)T.k[0] | ((unsigned)T.k[1] << 16), T23 = (unsigned)T.k[2] | ((unsigned)T.k[3] << 16);
+    const unsigned T45 = (unsigned)T.k[4] | ((unsigned)T.k[5] << 16), T6 = (unsigned)T.k[6];
+    // odd rows start one u16 later: re-pair with a 2-byte funnel shift
+    unsigned o0 = __builtin_amdgcn_alignbyte(e1, e0, 2), o1 = __builtin_amdgcn_alignbyte(e2, e1, 2), o2 = __builtin_amdgcn_alignbyte(e3, e2, 2),
+             o3 = __builtin_amdgcn_alignbyte(e4, e3, 2);
+#define BL_D2(a, b, c) __builtin_amdgcn_udot2(__builtin_bit_cast(bl_ushort2, (unsigned)(a)), __builtin_bit_cast(bl_ushort2, (unsigned)(b)), (c), false)
+    unsigned s0 = BL_D2(e0, T01, BL_D2(e1, T23, BL_D2(e2, T45, BL_D2(e3, T6, 0u))));
+    unsigned s1 = BL_D2(o0, T01, BL_D2(o1, T23, BL_D2(o2, T45, BL_D2(o3, T6, 0u))));
+    unsigned s2 = BL_D2(e1, T01, BL_D2(e2, T23, BL_D2(e3, T45, BL_D2(e4, T6, 0u))));
+    unsigned s3 = BL_D2(o1, T01, BL_D2(o2, T23, BL_D2(o3, T45, BL_D2(e4 >> 16, T6, 0u))));
+#undef BL_D2
+    const int gx = x0 + x;
+    if (gx < w) {
+      unsigned sv[4] = {s0, s1, s2, s3};
 #pragma unroll
-      for (int t = 0; t < 7; t++) v += T.k[t] * (int)sh[ty + t][tx];
-      dp[(size_t)y * pitch + x] = (u8)min(255, (v + 32768) >> 16);
+      for (int j = 0; j < 4; j++) {
+        int gy = y0 + r0 + j;
+        if (gy < h) dp[(size_t)gy * pitch + gx] = (u8)min(255u, (sv[j] + 32768u) >> 16);
+      }
     }
   }
 }
