@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic streams generated per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=10)
+    ap.add_argument("--stages", type=lambda v: int(v, 0), default=None,
+                    help="diagnostic: MVO_STAGE_* mask to run instead of the full step (the line then lists stages_missing)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -107,8 +109,10 @@ def main():
     for s in range(B):
         ctx.batch_set_landmarks(s, lmf(ctx.batch_get_tracks(s)))
 
-    stages = _lib.STAGE_ALL
-    stages_missing = []
+    stages = _lib.STAGE_ALL if args.stages is None else args.stages
+    names = {_lib.STAGE_LK: "lk", _lib.STAGE_PNP: "pnp", _lib.STAGE_HF: "ransac_hf", _lib.STAGE_ORB: "orb",
+             _lib.STAGE_MATCH: "match", _lib.STAGE_TRIANG: "triangulate"}
+    stages_missing = [n for b, n in names.items() if not stages & b]
 
     for k in range(Wm):
         ctx.batch_step(1 + k, stages)
@@ -132,7 +136,7 @@ def main():
     dt = parallel.max_over_ranks(dt, dist, device="cuda")
 
     prof = {}
-    for name in ("frame_fanout", "lk_pyramid", "lk_track", "lk_filter", "orb_detect", "orb_describe", "match", "pnp",
+    for name in ("frame_fanout", "lk_pyramid", "lk_track", "lk_filter", "orb_detect", "orb_blur", "orb_describe", "match", "pnp",
                  "ransac_h", "ransac_f", "triangulate"):
         ms, n = ctx.profile_read(name)
         if n:

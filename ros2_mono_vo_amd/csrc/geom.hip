@@ -7,14 +7,14 @@
 //   cv::triangulatePoints + convertPointsFromHomogeneous             reference src/tracker.cpp:149-152
 //   cv::recoverPose                                                  reference src/initializer.cpp:236
 //
-// ransac_kernel<Model>: ONE WORKGROUP PER PROBLEM (camera stream), so a batch of B streams is B
+// ransac_kernel<Model>: ONE WAVEFRONT PER PROBLEM (camera stream), so a batch of B streams is B single-wave
 // workgroups in one launch.  OpenCV's loop is sequential (adaptive iteration count, "strictly better"
 // update, data-dependent RNG consumption), so each round does
 //   1. lane 0 draws 64 candidate samples from cv::RNG((uint64)-1) in OpenCV's order,
 //   2. 64 lanes run checkSubset in parallel; an ordered ballot compaction turns passing candidates into
 //      RANSAC iterations (a failing candidate is exactly OpenCV's "retry with the next draws"),
 //   3. one hypothesis per lane: minimal solver (4-pt H / 7-pt F / 5-pt EPnP) in private memory,
-//   4. 256 lanes score (hypothesis = lane % 64, point quarter = lane / 64): integer inlier counts,
+//   4. every lane scores its own hypothesis over all points (uniform point loads): integer inlier counts,
 //   5. lane 0 replays the hypotheses in order applying the consensus update and RANSACUpdateNumIters,
 // and stops as soon as iter >= niters — the speculative tail of a round is simply discarded, which is
 // unobservable because nothing after the loop reads the RNG.  The consensus mask is then recomputed for
@@ -40,13 +40,15 @@ struct RansacArgs {
 };
 
 #define RS_CH 64   // candidate samples per round (one wavefront of private solvers; wider rounds thrash L2 with scratch)
-#define RS_PARTS (256 / RS_CH)
-#ifndef RS_WAVES_PER_EU
-#define RS_WAVES_PER_EU 1
-#endif
+// Threads per problem.  One wavefront: the solvers need 200-400 VGPRs, and a 4-wave workgroup parked three idle waves
+// of that size on every SIMD of its CU, starving the image kernels (ORB) that run beside it on the main stream.  With
+// one wave per stream a launch occupies one SIMD per stream and scoring is a per-lane loop over uniform point loads.
+#define RS_T 64
+#define RS_PARTS (RS_T / RS_CH)
+#define RS_NW (RS_T / 64)
 
 template <class M>
-__global__ __launch_bounds__(256, RS_WAVES_PER_EU) void ransac_kernel(RansacArgs A) {
+__global__ __launch_bounds__(RS_T) void ransac_kernel(RansacArgs A) {
   __shared__ int s_att[RS_CH][M::MP];
   __shared__ int s_idx[RS_CH][M::MP];
   __shared__ double s_models[RS_CH][M::MAXM][M::MS];
@@ -54,8 +56,8 @@ __global__ __launch_bounds__(256, RS_WAVES_PER_EU) void ransac_kernel(RansacArgs
   __shared__ int s_cnt[RS_CH][M::MAXM];
   __shared__ double s_best[M::MS];
   __shared__ int s_ctl[8];  // 0: npass, 1: done, 2: maxGood, 3: iter, 4: niters, 5: consec_fail, 6: ok, 7: models scored
-  __shared__ int s_wpass[4];
-  __shared__ unsigned long long s_wmask[4];
+  __shared__ int s_wpass[RS_NW];
+  __shared__ unsigned long long s_wmask[RS_NW];
   __shared__ unsigned long long s_rng;
 
   const int slot = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(256, RS_WAVES_PER_EU) void ransac_kernel(RansacArgs
   const float t = (float)(A.thr * A.thr);
 
   if (count < M::MP) {
-    for (int i = tid; i < count; i += 256) mask[i] = 0;
+    for (int i = tid; i < count; i += RS_T) mask[i] = 0;
     if (tid == 0) { result[0] = 0; result[1] = 0; result[2] = 0; result[3] = 0; result[4] = 0; }
     return;
   }
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256, RS_WAVES_PER_EU) void ransac_kernel(RansacArgs
     }
     __syncthreads();
     int ok = s_ctl[6];
-    for (int i = tid; i < count; i += 256) mask[i] = ok ? 1 : 0;
+    for (int i = tid; i < count; i += RS_T) mask[i] = ok ? 1 : 0;
     if (tid == 0) { result[0] = ok; result[1] = ok ? count : 0; result[2] = 1; result[3] = 1; result[4] = 1; }
     return;
   }
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256, RS_WAVES_PER_EU) void ransac_kernel(RansacArgs
           sc.init(A.P, &s_models[hyp][q][0]);
           int good = 0;
           for (int i = part; i < count; i += RS_PARTS) good += sc.err(m1 + (size_t)i * M::PT1, m2 + (size_t)i * M::PT2) <= t;
-          atomicAdd(&s_cnt[hyp][q], good);
+          if (RS_PARTS == 1) s_cnt[hyp][q] = good; else atomicAdd(&s_cnt[hyp][q], good);
         }
       }
     }
@@ -219,10 +221,10 @@ __global__ __launch_bounds__(256, RS_WAVES_PER_EU) void ransac_kernel(RansacArgs
   if (maxGood > 0) {
     typename M::Scorer sc;
     sc.init(A.P, s_best);
-    for (int i = tid; i < count; i += 256) mask[i] = sc.err(m1 + (size_t)i * M::PT1, m2 + (size_t)i * M::PT2) <= t ? 1 : 0;
+    for (int i = tid; i < count; i += RS_T) mask[i] = sc.err(m1 + (size_t)i * M::PT1, m2 + (size_t)i * M::PT2) <= t ? 1 : 0;
     if (tid < M::MS) out_model[tid] = s_best[tid];
   } else {
-    for (int i = tid; i < count; i += 256) mask[i] = 0;
+    for (int i = tid; i < count; i += RS_T) mask[i] = 0;
   }
   if (tid == 0) { result[0] = maxGood > 0; result[1] = maxGood; result[2] = s_ctl[3]; result[3] = s_ctl[4]; result[4] = s_ctl[7]; }
 }
@@ -722,7 +724,7 @@ static void launch_ransac(mvo_ctx* ctx, hipStream_t st, int nslots, const float*
   A.m1 = m1; A.m2 = m2; A.stride1 = stride1; A.stride2 = stride2; A.n = d_n;
   A.thr = thr; A.conf = conf; A.max_iters = max_iters; A.cap = ctx->maxpts; A.P = P;
   A.mask = mask; A.mask_stride = mask_stride; A.model = model; A.result = result;
-  hipLaunchKernelGGL(ransac_kernel<M>, dim3(nslots), dim3(256), 0, st, A);
+  hipLaunchKernelGGL(ransac_kernel<M>, dim3(nslots), dim3(RS_T), 0, st, A);
 }
 
 // Device-level drivers used by the pipeline (inputs already resident, all slots per launch).

@@ -53,9 +53,9 @@ __global__ __launch_bounds__(256) void pyrdown_kernel(ImgSet src, ImgSet dst) {
   }
 }
 
-static void launch_pyrdown(mvo_ctx* ctx, const ImgSet& s, const ImgSet& d, int nslots) {
+static void launch_pyrdown(mvo_ctx* ctx, const ImgSet& s, const ImgSet& d, int nslots, hipStream_t st) {
   dim3 grid((d.w + PD_TW - 1) / PD_TW, (d.h + PD_TH - 1) / PD_TH, nslots);
-  hipLaunchKernelGGL(pyrdown_kernel, grid, dim3(256), 0, ctx->stream, s, d);
+  hipLaunchKernelGGL(pyrdown_kernel, grid, dim3(256), 0, st, s, d);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -357,13 +357,15 @@ static ImgSet lk_imgset(mvo_ctx* ctx, int set, const LkLevels& L, int level) {
 }
 
 // Build levels 1.. of pyramid set `set` for `nslots` slots (level 0 already resident).
-int lk_build_pyramid(mvo_ctx* ctx, int set, const LkLevels& L, int nslots) {
-  for (int l = 1; l < L.n; l++) launch_pyrdown(ctx, lk_imgset(ctx, set, L, l - 1), lk_imgset(ctx, set, L, l), nslots);
+int lk_build_pyramid(mvo_ctx* ctx, int set, const LkLevels& L, int nslots, hipStream_t st) {
+  if (!st) st = ctx->stream;
+  for (int l = 1; l < L.n; l++) launch_pyrdown(ctx, lk_imgset(ctx, set, L, l - 1), lk_imgset(ctx, set, L, l), nslots, st);
   return MVO_OK;
 }
 
 // Track d_prev_pts -> d_next_pts for `nslots` slots between pyramid sets prev_set and cur_set.
-int lk_track_device(mvo_ctx* ctx, int prev_set, int cur_set, const LkLevels& L, int nslots, int max_n) {
+int lk_track_device(mvo_ctx* ctx, int prev_set, int cur_set, const LkLevels& L, int nslots, int max_n, hipStream_t st) {
+  if (!st) st = ctx->stream;
   LkArgs A;
   memset(&A, 0, sizeof(A));
   for (int l = 0; l < L.n; l++) {
@@ -384,7 +386,7 @@ int lk_track_device(mvo_ctx* ctx, int prev_set, int cur_set, const LkLevels& L, 
   A.min_eig = ctx->cfg.lk_min_eig;
   if (max_n <= 0) return MVO_OK;
   dim3 grid((max_n + 3) / 4, nslots);
-  hipLaunchKernelGGL(lk_track_kernel, grid, dim3(256), 0, ctx->stream, A);
+  hipLaunchKernelGGL(lk_track_kernel, grid, dim3(256), 0, st, A);
   return MVO_OK;
 }
 
@@ -395,7 +397,7 @@ extern "C" int mvo_pyrdown(mvo_ctx* ctx, const uint8_t* src, int w, int h, int s
   ImgSet s = lk_imgset(ctx, 0, L, 0), d = lk_imgset(ctx, 0, L, 1);
   int rc = upload_gray(ctx, src, w, h, stride, 1, s.base, s.pitch, 0);
   if (rc) return rc;
-  launch_pyrdown(ctx, s, d, 1);
+  launch_pyrdown(ctx, s, d, 1, ctx->stream);
   MVO_HIP(hipMemcpy2DAsync(dst, dstride, d.base, d.pitch, d.w, d.h, hipMemcpyDeviceToHost, ctx->stream));
   MVO_HIP(hipStreamSynchronize(ctx->stream));
   return MVO_OK;

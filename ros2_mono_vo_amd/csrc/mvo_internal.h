@@ -126,6 +126,7 @@ struct OrbState {
   int* h_sel = nullptr;
   mvo_keypoint* h_kp = nullptr;
   u8* h_desc = nullptr;
+  hipEvent_t ev_counts = nullptr, ev_cand = nullptr;  // phase boundaries of the split detect (orb_detect_enqueue / orb_select)
 };
 
 
@@ -180,8 +181,17 @@ int pipe_state_create(mvo_ctx* ctx);
 void pipe_state_destroy(mvo_ctx* ctx);
 
 // device-level stage drivers (all slots per launch)
-int lk_build_pyramid(mvo_ctx* ctx, int set, const LkLevels& L, int nslots);
-int lk_track_device(mvo_ctx* ctx, int prev_set, int cur_set, const LkLevels& L, int nslots, int max_n);
+int lk_build_pyramid(mvo_ctx* ctx, int set, const LkLevels& L, int nslots, hipStream_t st = nullptr);
+int lk_track_device(mvo_ctx* ctx, int prev_set, int cur_set, const LkLevels& L, int nslots, int max_n, hipStream_t st = nullptr);
+// ORB in three phases on ctx->stream so that a caller can put other GPU work beside the host-side selection:
+//   orb_detect_enqueue  pyramid, FAST+NMS, ordered compaction, async copy of the counts           (no host wait)
+//   orb_select          waits for the counts, Harris + candidate copy (+ the blurred pyramid, which does not depend
+//                       on the selection), then OpenCV's retainBest passes on the host; uploads the selection
+//   orb_describe_enqueue  IC angle + rBRIEF for the selection; `to_host` also copies key-points/descriptors back and waits
+// orb_run is the three in a row.
+int orb_detect_enqueue(mvo_ctx* ctx, int w, int h, int nslots);
+int orb_select(mvo_ctx* ctx, int w, int h, int nslots, bool describe, std::vector<int>& kp_base);
+int orb_describe_enqueue(mvo_ctx* ctx, int w, int h, int nslots, bool describe, bool to_host, const std::vector<int>& kp_base);
 int orb_run(mvo_ctx* ctx, int w, int h, int nslots, bool describe, std::vector<int>& kp_base);
 int match_device(mvo_ctx* ctx, int nslots, int max_nq, double ratio);
 int geom_ransac_h(mvo_ctx* ctx, int nslots, const float* p1, const float* p2, const int* d_n, double thr, int max_iters, double conf,

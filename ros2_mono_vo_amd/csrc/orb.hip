@@ -647,6 +647,8 @@ int orb_state_create(mvo_ctx* ctx) {
   MVO_HIP(hipHostMalloc(&o->h_sel, (size_t)o->kp_cap * sizeof(int), hipHostMallocDefault));
   MVO_HIP(hipHostMalloc(&o->h_kp, (size_t)o->kp_cap * sizeof(mvo_keypoint), hipHostMallocDefault));
   MVO_HIP(hipHostMalloc(&o->h_desc, (size_t)o->kp_cap * 32, hipHostMallocDefault));
+  MVO_HIP(hipEventCreateWithFlags(&o->ev_counts, hipEventDisableTiming));
+  MVO_HIP(hipEventCreateWithFlags(&o->ev_cand, hipEventDisableTiming));
   return MVO_OK;
 }
 
@@ -660,6 +662,8 @@ void orb_state_destroy(mvo_ctx* ctx) {
   void* hst[] = {o->h_counts, o->h_cs, o->h_ch, o->h_sel, o->h_kp, o->h_desc};
   for (void* p : hst)
     if (p) (void)hipHostFree(p);
+  if (o->ev_counts) (void)hipEventDestroy(o->ev_counts);
+  if (o->ev_cand) (void)hipEventDestroy(o->ev_cand);
   delete o;
   ctx->orb = nullptr;
 }
@@ -713,40 +717,60 @@ static int orb_detect_device(mvo_ctx* ctx, const OrbGeom& G, int nslots) {
   return MVO_OK;
 }
 
-// Fetch per-slot / per-level candidate counts (synchronises). h_counts: [B][8] lvl counts, then [B+1] slot bases.
-static int orb_fetch_counts(mvo_ctx* ctx, int nslots) {
-  OrbState* o = ctx->orb;
-  MVO_HIP(hipMemcpyAsync(o->h_counts, o->d_lvl_cnt, (size_t)nslots * MVO_ORB_LEVELS * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  MVO_HIP(hipMemcpyAsync(o->h_counts + (size_t)nslots * MVO_ORB_LEVELS, o->d_slot_base, (size_t)(nslots + 1) * sizeof(int),
-                         hipMemcpyDeviceToHost, ctx->stream));
-  MVO_HIP(hipStreamSynchronize(ctx->stream));
-  int total = o->h_counts[(size_t)nslots * MVO_ORB_LEVELS + nslots];
-  if (total > o->cand_cap) { ctx->set_error("ORB candidate capacity exceeded"); return MVO_E_CAPACITY; }
-  return MVO_OK;
+static void orb_geom_for(mvo_ctx* ctx, int w, int h, OrbGeom& G) {
+  orb_geometry(w, h, ctx->cfg.nfeatures, ORB_EDGE, G);
+  G.slot_stride = ctx->orb->slot_bytes;
 }
 
-// Full batched detect (+ optional describe).  Level 0 of each slot must be resident in orb->d_pyr.
-// Outputs land in h_kp / h_desc (dense over slots); kp_base[s]..kp_base[s+1] is slot s's range.
-int orb_run(mvo_ctx* ctx, int w, int h, int nslots, bool describe, std::vector<int>& kp_base) {
+// Phase 1.  Level 0 of each slot must be resident in orb->d_pyr.  h_counts: [B][8] lvl counts, then [B+1] slot bases.
+int orb_detect_enqueue(mvo_ctx* ctx, int w, int h, int nslots) {
   OrbState* o = ctx->orb;
-  hipStream_t st = ctx->stream;
   OrbGeom G;
-  orb_geometry(w, h, ctx->cfg.nfeatures, ORB_EDGE, G);
-  G.slot_stride = o->slot_bytes;
+  orb_geom_for(ctx, w, h, G);
   int rc;
   { ProfScope ps(ctx, "orb_detect"); rc = orb_detect_device(ctx, G, nslots); }
   if (rc) return rc;
-  if ((rc = orb_fetch_counts(ctx, nslots))) return rc;
+  MVO_HIP(hipMemcpyAsync(o->h_counts, o->d_lvl_cnt, (size_t)nslots * MVO_ORB_LEVELS * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  MVO_HIP(hipMemcpyAsync(o->h_counts + (size_t)nslots * MVO_ORB_LEVELS, o->d_slot_base, (size_t)(nslots + 1) * sizeof(int),
+                         hipMemcpyDeviceToHost, ctx->stream));
+  MVO_HIP(hipEventRecord(o->ev_counts, ctx->stream));
+  return MVO_OK;
+}
+
+static void orb_blur_enqueue(mvo_ctx* ctx, const OrbGeom& G, int nslots) {
+  OrbState* o = ctx->orb;
+  BlurTaps T;
+  static const int k0[7] = {18, 34, 49, 55, 49, 34, 18};
+  static const int k1[7] = {18, 34, 48, 56, 48, 34, 18};
+  for (int i = 0; i < 7; i++) T.k[i] = ctx->cfg.orb_blur_mode ? k1[i] : k0[i];
+  for (int l = 0; l < G.nlevels; l++) {
+    dim3 grid((G.w[l] + BL_W - 1) / BL_W, (G.h[l] + BL_H - 1) / BL_H, nslots);
+    hipLaunchKernelGGL(blur7_kernel, grid, dim3(256), 0, ctx->stream, o->d_pyr, o->d_blur, G.slot_stride, G.off[l], G.w[l], G.h[l],
+                       G.pitch[l], T);
+  }
+}
+
+// Phase 2.  kp_base[s]..kp_base[s+1] is slot s's range in the dense selection (d_sel / h_sel).
+int orb_select(mvo_ctx* ctx, int w, int h, int nslots, bool describe, std::vector<int>& kp_base) {
+  OrbState* o = ctx->orb;
+  hipStream_t st = ctx->stream;
+  OrbGeom G;
+  orb_geom_for(ctx, w, h, G);
+  MVO_HIP(hipEventSynchronize(o->ev_counts));
   const int* lvl = o->h_counts;
   const int* sbase = o->h_counts + (size_t)nslots * MVO_ORB_LEVELS;
   int total = sbase[nslots];
+  if (total > o->cand_cap) { ctx->set_error("ORB candidate capacity exceeded"); return MVO_E_CAPACITY; }
   kp_base.assign(nslots + 1, 0);
   if (total == 0) return MVO_OK;
   hipLaunchKernelGGL(harris_kernel, dim3((total + 255) / 256), dim3(256), 0, st, o->d_pyr, G, o->d_cx, o->d_cy, o->d_cl,
                      o->d_cslot, o->d_slot_base, nslots, o->d_ch, o->cand_cap);
   MVO_HIP(hipMemcpyAsync(o->h_cs, o->d_cs, (size_t)total, hipMemcpyDeviceToHost, st));
   MVO_HIP(hipMemcpyAsync(o->h_ch, o->d_ch, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, st));
-  MVO_HIP(hipStreamSynchronize(st));
+  MVO_HIP(hipEventRecord(o->ev_cand, st));
+  // the blurred pyramid does not depend on the selection: it runs on the device while the host selects
+  if (describe) { ProfScope ps(ctx, "orb_blur"); orb_blur_enqueue(ctx, G, nslots); }
+  MVO_HIP(hipEventSynchronize(o->ev_cand));
   // ---- host: OpenCV's two retainBest passes per level, on responses only ---------------------------
   // Streams are independent, so the per-slot selections run on a few host threads; the selected candidate
   // indices are then concatenated in slot order.
@@ -788,26 +812,39 @@ int orb_run(mvo_ctx* ctx, int w, int h, int nslots, bool describe, std::vector<i
   kp_base[nslots] = nsel;
   if (nsel == 0) return MVO_OK;
   MVO_HIP(hipMemcpyAsync(o->d_sel, o->h_sel, (size_t)nsel * sizeof(int), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(ic_angle_kernel, dim3((nsel + 3) / 4), dim3(256), 0, st, o->d_pyr, G, o->d_sel, nsel, o->d_cx, o->d_cy,
-                     o->d_cl, o->d_cslot, o->d_ch, o->d_umax, o->d_kp);
-  if (describe) {
-    ProfScope ps(ctx, "orb_describe");
-    BlurTaps T;
-    static const int k0[7] = {18, 34, 49, 55, 49, 34, 18};
-    static const int k1[7] = {18, 34, 48, 56, 48, 34, 18};
-    for (int i = 0; i < 7; i++) T.k[i] = ctx->cfg.orb_blur_mode ? k1[i] : k0[i];
-    for (int l = 0; l < G.nlevels; l++) {
-      dim3 grid((G.w[l] + BL_W - 1) / BL_W, (G.h[l] + BL_H - 1) / BL_H, nslots);
-      hipLaunchKernelGGL(blur7_kernel, grid, dim3(256), 0, st, o->d_pyr, o->d_blur, G.slot_stride, G.off[l], G.w[l], G.h[l],
-                         G.pitch[l], T);
-    }
-    hipLaunchKernelGGL(brief_kernel, dim3((nsel + 7) / 8), dim3(256), 0, st, o->d_blur, G, o->d_sel, nsel, o->d_cl, o->d_cslot,
-                       o->d_kp, o->d_pattern, o->d_desc);
-    MVO_HIP(hipMemcpyAsync(o->h_desc, o->d_desc, (size_t)nsel * 32, hipMemcpyDeviceToHost, st));
-  }
-  MVO_HIP(hipMemcpyAsync(o->h_kp, o->d_kp, (size_t)nsel * sizeof(mvo_keypoint), hipMemcpyDeviceToHost, st));
-  MVO_HIP(hipStreamSynchronize(st));
   return MVO_OK;
+}
+
+// Phase 3.  Outputs stay in d_kp / d_desc (dense over slots); `to_host` mirrors them into h_kp / h_desc and waits.
+int orb_describe_enqueue(mvo_ctx* ctx, int w, int h, int nslots, bool describe, bool to_host, const std::vector<int>& kp_base) {
+  OrbState* o = ctx->orb;
+  hipStream_t st = ctx->stream;
+  OrbGeom G;
+  orb_geom_for(ctx, w, h, G);
+  const int nsel = kp_base.empty() ? 0 : kp_base[nslots];
+  if (nsel == 0) return MVO_OK;
+  {
+    ProfScope ps(ctx, "orb_describe");
+    hipLaunchKernelGGL(ic_angle_kernel, dim3((nsel + 3) / 4), dim3(256), 0, st, o->d_pyr, G, o->d_sel, nsel, o->d_cx, o->d_cy,
+                       o->d_cl, o->d_cslot, o->d_ch, o->d_umax, o->d_kp);
+    if (describe)
+      hipLaunchKernelGGL(brief_kernel, dim3((nsel + 7) / 8), dim3(256), 0, st, o->d_blur, G, o->d_sel, nsel, o->d_cl, o->d_cslot,
+                         o->d_kp, o->d_pattern, o->d_desc);
+  }
+  if (to_host) {
+    if (describe) MVO_HIP(hipMemcpyAsync(o->h_desc, o->d_desc, (size_t)nsel * 32, hipMemcpyDeviceToHost, st));
+    MVO_HIP(hipMemcpyAsync(o->h_kp, o->d_kp, (size_t)nsel * sizeof(mvo_keypoint), hipMemcpyDeviceToHost, st));
+    MVO_HIP(hipStreamSynchronize(st));
+  }
+  return MVO_OK;
+}
+
+// Full batched detect (+ optional describe); outputs also land in h_kp / h_desc.
+int orb_run(mvo_ctx* ctx, int w, int h, int nslots, bool describe, std::vector<int>& kp_base) {
+  int rc;
+  if ((rc = orb_detect_enqueue(ctx, w, h, nslots))) return rc;
+  if ((rc = orb_select(ctx, w, h, nslots, describe, kp_base))) return rc;
+  return orb_describe_enqueue(ctx, w, h, nslots, describe, true, kp_base);
 }
 
 static int orb_upload(mvo_ctx* ctx, const uint8_t* img, int w, int h, int stride, int channels, int slot) {

@@ -118,8 +118,9 @@ struct PipeState {
   double* d_kf_pose = nullptr;  // [B][8] T_cw of the last key-frame (rvec, tvec)
   int* d_ntri = nullptr;      // [B]
   // side streams: the latency-bound RANSAC chains run beside ORB (they only depend on the LK survivors)
-  hipStream_t s_pnp = nullptr, s_hf = nullptr;
-  hipEvent_t ev_lk = nullptr, ev_pnp = nullptr, ev_hf = nullptr;
+  // s_lk carries pyramid + LK + filter (high priority: the RANSAC chains hang off it), main stream carries ORB.
+  hipStream_t s_lk = nullptr, s_pnp = nullptr, s_hf = nullptr;
+  hipEvent_t ev_frame = nullptr, ev_lk = nullptr, ev_pnp = nullptr, ev_hf = nullptr;
   int trk_max_n = 0;  // host-side bound on the per-slot track count (grid sizing)
   int kf_max_n = 0;   // host-side bound on the key-frame descriptor count
 };
@@ -151,8 +152,14 @@ int pipe_state_create(mvo_ctx* ctx) {
   MVO_HIP(hipMalloc(&p->d_tri_ok, np));
   MVO_HIP(hipMalloc(&p->d_kf_pose, (size_t)ctx->B * 8 * sizeof(double)));
   MVO_HIP(hipMalloc(&p->d_ntri, ctx->B * sizeof(int)));
-  MVO_HIP(hipStreamCreateWithFlags(&p->s_pnp, hipStreamNonBlocking));
-  MVO_HIP(hipStreamCreateWithFlags(&p->s_hf, hipStreamNonBlocking));
+  {
+    int prio_lo = 0, prio_hi = 0;  // numerically lower = higher priority
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    MVO_HIP(hipStreamCreateWithPriority(&p->s_lk, hipStreamNonBlocking, prio_hi));
+    MVO_HIP(hipStreamCreateWithPriority(&p->s_pnp, hipStreamNonBlocking, prio_hi));
+    MVO_HIP(hipStreamCreateWithFlags(&p->s_hf, hipStreamNonBlocking));
+  }
+  MVO_HIP(hipEventCreateWithFlags(&p->ev_frame, hipEventDisableTiming));
   MVO_HIP(hipEventCreateWithFlags(&p->ev_lk, hipEventDisableTiming));
   MVO_HIP(hipEventCreateWithFlags(&p->ev_pnp, hipEventDisableTiming));
   MVO_HIP(hipEventCreateWithFlags(&p->ev_hf, hipEventDisableTiming));
@@ -172,6 +179,8 @@ void pipe_state_destroy(mvo_ctx* ctx) {
                    p->d_kf_has, p->d_kf_lm, p->d_cur_has, p->d_cur_lmk, p->d_winner, p->d_tri, p->d_tri_ok, p->d_kf_pose, p->d_ntri};
     for (void* q : dev) (void)hipFree(q);
     if (p->h_ints) (void)hipHostFree(p->h_ints);
+    if (p->s_lk) { (void)hipStreamSynchronize(p->s_lk); (void)hipStreamDestroy(p->s_lk); }
+    if (p->ev_frame) (void)hipEventDestroy(p->ev_frame);
     if (p->s_pnp) { (void)hipStreamSynchronize(p->s_pnp); (void)hipStreamDestroy(p->s_pnp); }
     if (p->s_hf) { (void)hipStreamSynchronize(p->s_hf); (void)hipStreamDestroy(p->s_hf); }
     if (p->ev_lk) (void)hipEventDestroy(p->ev_lk);
@@ -483,25 +492,34 @@ extern "C" int mvo_batch_step(mvo_ctx* ctx, int frame_idx, unsigned stages, mvo_
   LkLevels L = lk_levels(p->w, p->h, ctx->cfg.lk_win, ctx->cfg.lk_max_level);
   const int prev_set = ctx->lk_cur, cur_set = ctx->lk_cur ^ 1;
   memset(out, 0, sizeof(mvo_step_result) * B);
+  // Stream plan (all B camera streams per launch):
+  //   main   frame fan-out -> ORB detect -> [host: retainBest | device: blur] -> angle + rBRIEF -> match -> triangulate
+  //   s_lk   (waits for the fan-out) pyrDown pyramid -> LK -> status/err filter            -- beside ORB detect
+  //   s_pnp  (waits for LK) PnP RANSAC + refine        s_hf  (waits for LK) H RANSAC, F RANSAC
+  // so the host-side key-point selection overlaps LK and the RANSAC chains instead of idling the device.
   if ((rc = pipe_load_frame(ctx, frame_idx, cur_set))) return rc;
-  { ProfScope ps(ctx, "lk_pyramid"); lk_build_pyramid(ctx, cur_set, L, B); }
+  MVO_HIP(hipEventRecord(p->ev_frame, ctx->stream));
+  const bool do_orb = stages & MVO_STAGE_ORB;
+  if (do_orb && (rc = orb_detect_enqueue(ctx, p->w, p->h, B))) return rc;
+  MVO_HIP(hipStreamWaitEvent(p->s_lk, p->ev_frame, 0));
+  { ProfScope ps(ctx, "lk_pyramid", p->s_lk); lk_build_pyramid(ctx, cur_set, L, B, p->s_lk); }
   // pinned layout: hb[0..B) n_prev, [B..2B) n_tracked, [2B..3B) n_matches, [3B..4B) n_tri, [4B..5B) n_new_tracks,
   //                hr[0..8B) pnp result, [8B..16B) H result, [16B..24B) F result; hp: [B][8] pose
   int* hb = p->h_ints;
   int* hr = g->h_result;
   double* hp = g->h_model;
   if (stages & MVO_STAGE_LK) {
-    { ProfScope ps(ctx, "lk_track"); lk_track_device(ctx, prev_set, cur_set, L, B, p->trk_max_n); }
-    ProfScope ps(ctx, "lk_filter");
-    hipLaunchKernelGGL(lk_filter_compact_kernel, dim3(B), dim3(1024), 0, ctx->stream, ctx->d_next_pts, ctx->d_status, ctx->d_err,
+    { ProfScope ps(ctx, "lk_track", p->s_lk); lk_track_device(ctx, prev_set, cur_set, L, B, p->trk_max_n, p->s_lk); }
+    ProfScope ps(ctx, "lk_filter", p->s_lk);
+    hipLaunchKernelGGL(lk_filter_compact_kernel, dim3(B), dim3(1024), 0, p->s_lk, ctx->d_next_pts, ctx->d_status, ctx->d_err,
                        ctx->d_npts, p->d_lm, p->d_kf_pts, ctx->cfg.tracking_error_thresh, ctx->maxpts, p->d_cur_pts,
                        p->d_cur_lm, p->d_cur_kf, p->d_ncur);
-    MVO_HIP(hipMemcpyAsync(hb, ctx->d_npts, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    MVO_HIP(hipMemcpyAsync(hb + B, p->d_ncur, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MVO_HIP(hipMemcpyAsync(hb, ctx->d_npts, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, p->s_lk));
+    MVO_HIP(hipMemcpyAsync(hb + B, p->d_ncur, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, p->s_lk));
   }
+  MVO_HIP(hipEventRecord(p->ev_lk, p->s_lk));
   const bool do_pnp = (stages & MVO_STAGE_LK) && (stages & MVO_STAGE_PNP);
   const bool do_hf = (stages & MVO_STAGE_LK) && (stages & MVO_STAGE_HF);
-  if (do_pnp || do_hf) MVO_HIP(hipEventRecord(p->ev_lk, ctx->stream));
   if (do_pnp) {
     MVO_HIP(hipStreamWaitEvent(p->s_pnp, p->ev_lk, 0));
     { ProfScope ps(ctx, "pnp", p->s_pnp);
@@ -525,8 +543,9 @@ extern "C" int mvo_batch_step(mvo_ctx* ctx, int frame_idx, unsigned stages, mvo_
     MVO_HIP(hipEventRecord(p->ev_hf, p->s_hf));
   }
   std::vector<int> base;
-  if (stages & MVO_STAGE_ORB) {
-    if ((rc = orb_run(ctx, p->w, p->h, B, true, base))) return rc;
+  if (do_orb) {
+    if ((rc = orb_select(ctx, p->w, p->h, B, true, base))) return rc;
+    if ((rc = orb_describe_enqueue(ctx, p->w, p->h, B, true, false, base))) return rc;
     int mx = 0;
     if ((rc = pipe_publish_orb(ctx, base, &mx))) return rc;
     const bool do_match = stages & MVO_STAGE_MATCH;
@@ -536,6 +555,8 @@ extern "C" int mvo_batch_step(mvo_ctx* ctx, int frame_idx, unsigned stages, mvo_
       match_device(ctx, B, p->kf_max_n, ctx->cfg.lowes_distance_ratio);
       MVO_HIP(hipMemcpyAsync(hb + 2 * B, m->d_nout, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     }
+    // everything below rewrites the track arrays LK reads (d_prev_pts, d_lm, d_kf_pts, d_npts)
+    MVO_HIP(hipStreamWaitEvent(ctx->stream, p->ev_lk, 0));
     if (do_tri) {
       MVO_HIP(hipStreamWaitEvent(ctx->stream, p->ev_pnp, 0));  // the pose comes from the PnP side stream
       ProfScope ps(ctx, "triangulate");
@@ -558,12 +579,14 @@ extern "C" int mvo_batch_step(mvo_ctx* ctx, int frame_idx, unsigned stages, mvo_
     }
   } else if (stages & MVO_STAGE_LK) {
     // no key-frame: survivors become the next frame's tracks (src/tracker.cpp:331)
+    MVO_HIP(hipStreamWaitEvent(ctx->stream, p->ev_lk, 0));
     MVO_HIP(hipMemcpyAsync(ctx->d_prev_pts, p->d_cur_pts, np * 2 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     MVO_HIP(hipMemcpyAsync(p->d_lm, p->d_cur_lm, np * 3 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     MVO_HIP(hipMemcpyAsync(p->d_kf_pts, p->d_cur_kf, np * 2 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     MVO_HIP(hipMemcpyAsync(ctx->d_npts, p->d_ncur, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
   }
   // the LK survivors (d_cur_*) must not be overwritten by the next step before the side streams are done
+  MVO_HIP(hipStreamSynchronize(p->s_lk));
   if (do_pnp) MVO_HIP(hipStreamSynchronize(p->s_pnp));
   if (do_hf) MVO_HIP(hipStreamSynchronize(p->s_hf));
   MVO_HIP(hipStreamSynchronize(ctx->stream));
