@@ -39,16 +39,21 @@ struct RansacArgs {
   int* result;    // [B][8]: ok, n_inliers, iters_run, niters_final, models_scored
 };
 
-#define RS_CH 64   // candidate samples per round (one wavefront of private solvers; wider rounds thrash L2 with scratch)
+// Candidate samples per round = M::CH (16 for H / F / PnP): their solvers keep the dense matrices in a per-lane LDS
+// workspace, and 16 lanes of it are 25-37 KB per stream.  RANSAC on this path usually stops after a handful of
+// iterations (adaptive niters), so a round of 16 is rarely repeated; the other 48 lanes help with scoring.
 // Threads per problem.  One wavefront: the solvers need 200-400 VGPRs, and a 4-wave workgroup parked three idle waves
 // of that size on every SIMD of its CU, starving the image kernels (ORB) that run beside it on the main stream.  With
 // one wave per stream a launch occupies one SIMD per stream and scoring is a per-lane loop over uniform point loads.
 #define RS_T 64
-#define RS_PARTS (RS_T / RS_CH)
 #define RS_NW (RS_T / 64)
 
 template <class M>
 __global__ __launch_bounds__(RS_T) void ransac_kernel(RansacArgs A) {
+  constexpr int RS_CH = M::CH, RS_PARTS = RS_T / RS_CH;
+  // per-lane workspace stride: == 1 (mod 32) doubles, so lane-uniform 8-byte accesses of 16 lanes fall into distinct banks
+  constexpr int WSS = M::WS > 0 ? ((M::WS + 30) / 32) * 32 + 1 : 1;
+  __shared__ double s_ws[(M::WS > 0 ? RS_CH : 1) * WSS];
   __shared__ int s_att[RS_CH][M::MP];
   __shared__ int s_idx[RS_CH][M::MP];
   __shared__ double s_models[RS_CH][M::MAXM][M::MS];
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(RS_T) void ransac_kernel(RansacArgs A) {
       for (int i = 0; i < M::MP * M::PT1; i++) ms1[i] = m1[i];
       for (int i = 0; i < M::MP * M::PT2; i++) ms2[i] = m2[i];
       double models[M::MAXM * M::MS];
-      int nm = M::solve(A.P, ms1, ms2, models);
+      int nm = M::solve(A.P, ms1, ms2, models, s_ws);
       s_ctl[6] = nm > 0;
       if (nm > 0)
         for (int k = 0; k < M::MS; k++) out_model[k] = models[k];
@@ -99,6 +104,13 @@ __global__ __launch_bounds__(RS_T) void ransac_kernel(RansacArgs A) {
     return;
   }
 
+#ifdef RS_TIMING
+  long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tq = wall_clock64();
+#define RS_TICK(k) { long long tn = wall_clock64(); tm[k] += tn - tq; tq = tn; }
+#else
+#define RS_TICK(k)
+#endif
   for (;;) {
     // ---- 1. candidate samples, OpenCV's getSubset draw order (sequential RNG stream, lane 0) ----------
     if (tid == 0) {
@@ -119,6 +131,7 @@ __global__ __launch_bounds__(RS_T) void ransac_kernel(RansacArgs A) {
       s_rng = rng.state;
     }
     __syncthreads();
+    RS_TICK(0)
     // ---- 2. checkSubset in parallel (one candidate per lane) + ordered compaction over the 4 waves -------
     float ms1[M::MP * M::PT1], ms2[M::MP * M::PT2];
     bool pass = false;
@@ -141,14 +154,15 @@ __global__ __launch_bounds__(RS_T) void ransac_kernel(RansacArgs A) {
       // OpenCV gives up on an iteration after 10000 consecutive failing attempts: walk the pass bits in order
       int np = 0, run = s_ctl[5];
       bool abort_ = false;
-      for (int w = 0; w < RS_CH / 64; w++) {
+      constexpr int CPW = RS_CH < 64 ? RS_CH : 64;  // candidates held by one wave's ballot
+      for (int w = 0; w < RS_NW; w++) {
         unsigned long long m = s_wmask[w];
         np += __popcll(m);
-        if (m == 0) { run += 64; abort_ |= run >= 10000; }
+        if (m == 0) { run += CPW; abort_ |= run >= 10000; }
         else {
           int lead = __ffsll((long long)m) - 1;
           abort_ |= (run + lead) >= 10000;
-          run = __clzll(m);
+          run = __clzll(m) - (64 - CPW);  // failing candidates after the last passing one
         }
       }
       s_ctl[0] = np;
@@ -162,6 +176,7 @@ __global__ __launch_bounds__(RS_T) void ransac_kernel(RansacArgs A) {
     __syncthreads();
     if (s_ctl[1]) break;
     const int npass = s_ctl[0];
+    RS_TICK(1)
     // ---- 3. minimal solver, one hypothesis per lane; only as many as can still be consumed ---------------
     const int nsolve = min(npass, s_ctl[4] - s_ctl[3]);
     int nm = 0;
@@ -172,7 +187,7 @@ __global__ __launch_bounds__(RS_T) void ransac_kernel(RansacArgs A) {
         for (int k = 0; k < M::PT2; k++) ms2[i * M::PT2 + k] = m2[(size_t)id * M::PT2 + k];
       }
       double models[M::MAXM * M::MS];
-      nm = M::solve(A.P, ms1, ms2, models);
+      nm = M::solve(A.P, ms1, ms2, models, s_ws + (M::WS > 0 ? tid * WSS : 0));
       if (nm < 0) nm = 0;
       if (nm > M::MAXM) nm = M::MAXM;
       s_nmodels[tid] = nm;
@@ -180,6 +195,7 @@ __global__ __launch_bounds__(RS_T) void ransac_kernel(RansacArgs A) {
         for (int k = 0; k < M::MS; k++) s_models[tid][q][k] = models[q * M::MS + k];
     }
     __syncthreads();
+    RS_TICK(2)
     // ---- 4. scoring: hypothesis = tid % RS_CH, point partition = tid / RS_CH; integer inlier counts ------------
     {
       const int hyp = tid % RS_CH, part = tid / RS_CH;
@@ -195,6 +211,7 @@ __global__ __launch_bounds__(RS_T) void ransac_kernel(RansacArgs A) {
       }
     }
     __syncthreads();
+    RS_TICK(3)
     // ---- 5. ordered replay of OpenCV's consensus update -------------------------------------------------------
     if (tid == 0) {
       int maxGood = s_ctl[2], iter = s_ctl[3], niters = s_ctl[4], scored = s_ctl[7];
@@ -214,6 +231,7 @@ __global__ __launch_bounds__(RS_T) void ransac_kernel(RansacArgs A) {
       if (iter >= niters) s_ctl[1] = 1;
     }
     __syncthreads();
+    RS_TICK(4)
     if (s_ctl[1]) break;
   }
   // ---- consensus mask of the winning model ---------------------------------------------------------------------
@@ -227,6 +245,12 @@ __global__ __launch_bounds__(RS_T) void ransac_kernel(RansacArgs A) {
     for (int i = tid; i < count; i += RS_T) mask[i] = 0;
   }
   if (tid == 0) { result[0] = maxGood > 0; result[1] = maxGood; result[2] = s_ctl[3]; result[3] = s_ctl[4]; result[4] = s_ctl[7]; }
+#ifdef RS_TIMING
+  RS_TICK(5)
+  if (tid == 0 && (slot == 0 || slot == 100))
+    printf("RS_TIMING MP=%d slot=%d n=%d iters=%d scored=%d | draw %lld check %lld solve %lld score %lld replay %lld mask %lld (100MHz ticks)\n", M::MP, slot, count,
+           s_ctl[3], s_ctl[7], tm[0], tm[1], tm[2], tm[3], tm[4], tm[5]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------

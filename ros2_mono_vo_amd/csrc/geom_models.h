@@ -3,7 +3,11 @@
 //   MP          sample size            MAXM   models per sample        MS   doubles per model
 //   PT1 / PT2   floats per point in set 1 / set 2
 //   check_subset(ms1, ms2)             OpenCV's Callback::checkSubset
-//   solve(P, ms1, ms2, models)         OpenCV's Callback::runKernel   -> number of models
+//   solve(P, ms1, ms2, models, ws)     OpenCV's Callback::runKernel   -> number of models
+//   CH          hypotheses solved per RANSAC round (lanes of the wavefront that run the solver)
+//   WS          doubles of per-lane LDS workspace `ws` for the solver's dense matrices (0: all in private memory).
+//               Private (scratch) matrices cost an L2 round trip per element and, with per-lane pivots (Jacobi
+//               eigen), 64 different cache lines per access; in LDS they cost a bank access.
 //   Scorer                             per-model constants + err(p1, p2) -> float (Callback::computeError)
 // Semantics: OpenCV 4.6 calib3d (fundam.cpp, solvepnp.cpp, epnp.cpp, calibration.cpp) as restated in
 // SURVEY.md Appendix A.5-A.7; arithmetic order matches oracle/orc_geom.cpp / orc_pnp.cpp.
@@ -18,6 +22,7 @@ struct ModelParams { CamK cam; };
 // ---------------------------------------------------------------------------------------------------
 struct HModel {
   static constexpr int MP = 4, MAXM = 1, MS = 9, PT1 = 2, PT2 = 2;
+  static constexpr int CH = 16, WS = 81 + 9 + 81;  // LtL, W, V
 
   __device__ static bool check_subset(const float* ms1, const float* ms2) {
     if (gl_have_collinear(ms1, 4) || gl_have_collinear(ms2, 4)) return false;
@@ -33,8 +38,8 @@ struct HModel {
   }
 
   // runKernel for `count` float points (count = 4 inside RANSAC)
-  __device__ GL_NOINLINE static int solve_n(const float* M, const float* m, int count, double* model) {
-    double LtL[81], W[9], V[81];
+  __device__ GL_NOINLINE static int solve_n(const float* M, const float* m, int count, double* model, double* ws) {
+    double *LtL = ws, *W = ws + 81, *V = ws + 90;
     double cMx = 0, cMy = 0, cmx = 0, cmy = 0, sMx = 0, sMy = 0, smx = 0, smy = 0;
     for (int i = 0; i < count; i++) {
       cmx += m[2 * i]; cmy += m[2 * i + 1];
@@ -71,8 +76,8 @@ struct HModel {
     for (int i = 0; i < 9; i++) model[i] = H0[i] * s;
     return 1;
   }
-  __device__ static int solve(const ModelParams&, const float* ms1, const float* ms2, double* models) {
-    return solve_n(ms1, ms2, 4, models);
+  __device__ static int solve(const ModelParams&, const float* ms1, const float* ms2, double* models, double* ws) {
+    return solve_n(ms1, ms2, 4, models, ws);
   }
 
   struct Scorer {
@@ -94,14 +99,15 @@ struct HModel {
 // ---------------------------------------------------------------------------------------------------
 struct FModel {
   static constexpr int MP = 7, MAXM = 3, MS = 9, PT1 = 2, PT2 = 2;
+  static constexpr int CH = 16, WS = 63 + 81 + 81 + 49;  // a, v, ta, tv
 
   __device__ static bool check_subset(const float* ms1, const float* ms2) {
     return !gl_have_collinear(ms1, 7) && !gl_have_collinear(ms2, 7);
   }
 
-  __device__ GL_NOINLINE static int solve(const ModelParams&, const float* m1, const float* m2, double* fmatrix) {
-    double a[7 * 9], w[7], v[9 * 9], c[4], r[3] = {0, 0, 0};
-    double ta[81], tv[49];
+  __device__ GL_NOINLINE static int solve(const ModelParams&, const float* m1, const float* m2, double* fmatrix, double* ws) {
+    double *a = ws, *v = ws + 63, *ta = ws + 144, *tv = ws + 225;
+    double w[7], c[4], r[3] = {0, 0, 0};
     double *f1, *f2;
     double t0, t1, t2;
     double m1cx = 0, m1cy = 0, m2cx = 0, m2cy = 0;
@@ -444,7 +450,9 @@ __device__ GL_NOINLINE double ep_compute_R_and_t(EpnpState& e, const double* ut,
 }
 
 // solvePnP(SOLVEPNP_EPNP) for 5 float correspondences -> rvec, tvec
-__device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const CamK& cam, double rvec[3], double tvec[3]) {
+// ws: 288 doubles (LDS).  [0,144) MtM, rotated in place into Ut by the SVD; [144,288) first M (2n x 12), then the SVD's V,
+// then the workspaces of the three small least-squares solves.
+__device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const CamK& cam, double rvec[3], double tvec[3], double* ws) {
   const int n = EP_N;
   EpnpState e;
   e.fu = cam.fx; e.fv = cam.fy; e.uc = cam.cx; e.vc = cam.cy;
@@ -493,9 +501,10 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
     }
   }
   // M (2n x 12), MtM, SVD
-  double ut[144];
+  double* ut = ws;
+  double* ws2 = ws + 144;
   {
-    double M[2 * EP_N * 12];
+    double* M = ws2;
     for (int i = 0; i < n; i++) {
       const double* as = &e.alphas[4 * i];
       double u = e.us[2 * i], v = e.us[2 * i + 1];
@@ -506,18 +515,19 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
         M2[3 * k] = 0.0; M2[3 * k + 1] = as[k] * e.fv; M2[3 * k + 2] = as[k] * (e.vc - v);
       }
     }
-    double mtm[144], d[12], tv[144];
+    double* mtm = ws;
+    double d[12];
     for (int a = 0; a < 12; a++)
       for (int b = a; b < 12; b++) {
         double s = 0;
         for (int i = 0; i < 2 * n; i++) s += M[i * 12 + a] * M[i * 12 + b];
         mtm[a * 12 + b] = mtm[b * 12 + a] = s;
       }
+    double* tv = ws2;  // M is dead from here on
     // Ut rows = left singular vectors = rows of the rotated A^T: run the one-sided Jacobi directly on mtm^T
     for (int i = 0; i < 12; i++)
       for (int j = i + 1; j < 12; j++) { double t = mtm[i * 12 + j]; mtm[i * 12 + j] = mtm[j * 12 + i]; mtm[j * 12 + i] = t; }
-    gl_jacobi_svd(mtm, 12, d, tv, 12, 12, 12);
-    for (int i = 0; i < 144; i++) ut[i] = mtm[i];
+    gl_jacobi_svd(mtm, 12, d, tv, 12, 12, 12);  // ut == mtm
   }
   double l_6x10[60], rho[6];
   {
@@ -554,7 +564,7 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
   {  // find_betas_approx_1
     double l[24], b4[4];
     for (int i = 0; i < 6; i++) { l[i * 4] = l_6x10[i * 10]; l[i * 4 + 1] = l_6x10[i * 10 + 1]; l[i * 4 + 2] = l_6x10[i * 10 + 3]; l[i * 4 + 3] = l_6x10[i * 10 + 6]; }
-    gl_solve_svd(l, 6, 4, rho, b4);
+    gl_solve_svd_ws(l, 6, 4, rho, b4, ws2, ws2 + 36);
     double* betas = Betas[1];
     if (b4[0] < 0) { betas[0] = sqrt(-b4[0]); betas[1] = -b4[1] / betas[0]; betas[2] = -b4[2] / betas[0]; betas[3] = -b4[3] / betas[0]; }
     else { betas[0] = sqrt(b4[0]); betas[1] = b4[1] / betas[0]; betas[2] = b4[2] / betas[0]; betas[3] = b4[3] / betas[0]; }
@@ -564,7 +574,7 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
   {  // find_betas_approx_2
     double l[18], b3[3];
     for (int i = 0; i < 6; i++) { l[i * 3] = l_6x10[i * 10]; l[i * 3 + 1] = l_6x10[i * 10 + 1]; l[i * 3 + 2] = l_6x10[i * 10 + 2]; }
-    gl_solve_svd(l, 6, 3, rho, b3);
+    gl_solve_svd_ws(l, 6, 3, rho, b3, ws2, ws2 + 36);
     double* betas = Betas[2];
     if (b3[0] < 0) { betas[0] = sqrt(-b3[0]); betas[1] = (b3[2] < 0) ? sqrt(-b3[2]) : 0.0; }
     else { betas[0] = sqrt(b3[0]); betas[1] = (b3[2] > 0) ? sqrt(b3[2]) : 0.0; }
@@ -577,7 +587,7 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
     double l[30], b5[5];
     for (int i = 0; i < 6; i++)
       for (int j = 0; j < 5; j++) l[i * 5 + j] = l_6x10[i * 10 + j];
-    gl_solve_svd(l, 6, 5, rho, b5);
+    gl_solve_svd_ws(l, 6, 5, rho, b5, ws2, ws2 + 36);
     double* betas = Betas[3];
     if (b5[0] < 0) { betas[0] = sqrt(-b5[0]); betas[1] = (b5[2] < 0) ? sqrt(-b5[2]) : 0.0; }
     else { betas[0] = sqrt(b5[0]); betas[1] = (b5[2] > 0) ? sqrt(b5[2]) : 0.0; }
@@ -600,10 +610,11 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
 
 struct PnPModel {
   static constexpr int MP = 5, MAXM = 1, MS = 6, PT1 = 3, PT2 = 2;
+  static constexpr int CH = 16, WS = 144 + 144;  // MtM -> Ut, and M / V / the small solves' workspaces
   __device__ static bool check_subset(const float*, const float*) { return true; }
-  __device__ static int solve(const ModelParams& P, const float* ms1, const float* ms2, double* model) {
+  __device__ static int solve(const ModelParams& P, const float* ms1, const float* ms2, double* model, double* ws) {
     double rvec[3], tvec[3];
-    gm_epnp5(ms1, ms2, P.cam, rvec, tvec);
+    gm_epnp5(ms1, ms2, P.cam, rvec, tvec, ws);
     for (int i = 0; i < 3; i++) { model[2 * i] = rvec[i]; model[2 * i + 1] = tvec[i]; }  // hconcat(rvec, tvec)
     return 1;
   }
@@ -845,8 +856,9 @@ __device__ GL_NOINLINE int em_solve5(const double* q1, const double* q2, double*
 
 struct EModel {
   static constexpr int MP = 5, MAXM = 10, MS = 9, PT1 = 2, PT2 = 2;
+  static constexpr int CH = 64, WS = 0;  // initialisation only (src/initializer.cpp), not on the per-frame path: private memory
   __device__ static bool check_subset(const float*, const float*) { return true; }
-  __device__ static int solve(const ModelParams& P, const float* ms1, const float* ms2, double* models) {
+  __device__ static int solve(const ModelParams& P, const float* ms1, const float* ms2, double* models, double*) {
     double q1[10], q2[10];
     for (int i = 0; i < 5; i++) {
       q1[2 * i] = ((double)ms1[2 * i] - P.cam.cx) / P.cam.fx; q1[2 * i + 1] = ((double)ms1[2 * i + 1] - P.cam.cy) / P.cam.fy;
