@@ -285,9 +285,12 @@ __global__ __launch_bounds__(1024) void mask_to_indices_kernel(const u8* __restr
   if (threadIdx.x == 0) result[(size_t)slot * 8 + 5] = s_base;
 }
 
-#define PR_T 256
-// deterministic block-wide sum of `K` doubles per thread: shuffle tree inside each wave, then the four wave
-// partials through LDS (2 barriers in total, fixed summation order).  s_red must hold 4*K doubles.
+// One wavefront per stream: the kernel needs ~500 VGPRs for its 78 double accumulators, and a 4-wave workgroup of
+// that size per stream took every SIMD of the chip for itself (ORB's kernels on the main stream stalled behind it).
+#define PR_T 64
+#define PR_NW (PR_T / 64)
+// deterministic block-wide sum of `K` doubles per thread: butterfly inside each wave (every lane ends with the same
+// bits), then the wave partials through LDS in a fixed order.  s_red must hold PR_NW*K doubles.
 template <int K>
 __device__ inline void block_sum(double* v, double* s_red, double* out /* [K], valid in all threads */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -295,10 +298,16 @@ __device__ inline void block_sum(double* v, double* s_red, double* out /* [K], v
     double x = v[k];
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
-    if (lane == 0) s_red[wave * K + k] = x;
+    if (PR_NW == 1) out[k] = x;
+    else if (lane == 0) s_red[wave * K + k] = x;
   }
+  if (PR_NW == 1) return;
   __syncthreads();
-  for (int k = 0; k < K; k++) out[k] = ((s_red[k] + s_red[K + k]) + s_red[2 * K + k]) + s_red[3 * K + k];
+  for (int k = 0; k < K; k++) {
+    double t = s_red[k];
+    for (int w = 1; w < PR_NW; w++) t += s_red[w * K + k];
+    out[k] = t;
+  }
   __syncthreads();
 }
 
@@ -317,7 +326,7 @@ struct PnpRefineArgs {
 // One workgroup per stream.  Sums over the inlier set are block reductions in a fixed order (the oracle
 // sums sequentially, so R,t agree to rounding, not bit for bit); the small dense solves run on lane 0.
 __global__ __launch_bounds__(PR_T) void pnp_refine_kernel(PnpRefineArgs A) {
-  __shared__ double s_red[4 * 78];
+  __shared__ double s_red[PR_NW * 78];
   __shared__ double s_sh[160];  // broadcast area
   __shared__ double s_mat[2 * 144 + 16];  // lane-0 dense solves work in LDS, not in scratch (latency)
   __shared__ int s_flag[4];
