@@ -136,7 +136,7 @@ def main():
     dt = parallel.max_over_ranks(dt, dist, device="cuda")
 
     prof = {}
-    for name in ("frame_fanout", "lk_pyramid", "lk_track", "lk_filter", "orb_detect", "orb_blur", "orb_describe", "match", "pnp",
+    for name in ("frame_fanout", "lk_pyramid", "lk_track", "lk_filter", "orb_detect", "orb_select", "orb_blur", "orb_describe", "match", "pnp",
                  "ransac_h", "ransac_f", "triangulate"):
         ms, n = ctx.profile_read(name)
         if n:

@@ -103,6 +103,13 @@ int mvo_orb_detect(mvo_ctx* ctx, const uint8_t* img, int w, int h, int stride, i
  * (x, y, score) triples, as cv::FAST(img, kps, threshold, true). */
 int mvo_fast9_nms(mvo_ctx* ctx, const uint8_t* img, int w, int h, int stride, int threshold, int* xys,
                   int cap, int* n);
+/* Building block exposed for parity tests: cv::KeyPointsFilter::retainBest(keypoints, n_keep) on an array of
+ * responses (what cv::ORB applies twice per pyramid level inside detectAndCompute, src/feature_processor.cpp:19-23).
+ * Writes the ORIGINAL indices of the survivors in the order OpenCV leaves them in the vector (std::nth_element +
+ * std::partition of libstdc++ 11); *out_n may exceed n_keep on ties with the n_keep-th response.  out_idx must
+ * hold n entries.  depth_limit < 0: introselect's own limit, 2*floor(log2 n); >= 0 overrides it (test hook for
+ * the heap-select branch). */
+int mvo_retain_best(mvo_ctx* ctx, const float* responses, int n, int n_keep, int depth_limit, int* out_idx, int* out_n);
 
 /* ---- a2: FeatureProcessor::find_matches (src/feature_processor.cpp:25-41) ------------------------
  * BFMatcher(NORM_HAMMING).knnMatch(q, t, 2) + Lowe ratio (m[0].distance < ratio * m[1].distance). */

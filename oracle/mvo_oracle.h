@@ -14,6 +14,7 @@ int orc_lk_track(const unsigned char* prev, const unsigned char* next, int w, in
                  int win, int max_level, int max_count, double epsilon, double min_eig_thr);
 
 int orc_fast9_nms(const unsigned char* img, int w, int h, int stride, int threshold, int* xys, int cap);
+int orc_retain_best(const float* resp, int n, int n_keep, int depth_limit, int* out_idx);
 int orc_orb_level_info(int w, int h, int nfeatures, int* lw, int* lh, float* scale, int* quota);
 int orc_resize_linear_exact(const unsigned char* src, int sw, int sh, int sstride, unsigned char* dst,
                             int dw, int dh, int dstride);

@@ -217,6 +217,28 @@ static void retain_best(std::vector<KP>& k, int n) {
   }
 }
 
+// Test hook: retainBest on bare responses, returning the original indices in the order the vector is left in.
+// depth_limit >= 0 calls libstdc++'s own __introselect with that limit (instead of 2*floor(log2 n)) so that the
+// heap-select branch can be exercised; the rest is nth_element's body verbatim in behaviour.
+extern "C" int orc_retain_best(const float* resp, int n, int n_keep, int depth_limit, int* out_idx) {
+  struct RI { float response; int idx; };
+  std::vector<RI> k(n);
+  for (int i = 0; i < n; i++) k[i] = {resp[i], i};
+  auto gt = [](const RI& a, const RI& b) { return a.response > b.response; };
+  if (n_keep >= 0 && k.size() > (size_t)n_keep) {
+    if (n_keep == 0) k.clear();
+    else {
+      if (depth_limit < 0) std::nth_element(k.begin(), k.begin() + n_keep - 1, k.end(), gt);
+      else std::__introselect(k.begin(), k.begin() + n_keep - 1, k.end(), (long)depth_limit, __gnu_cxx::__ops::__iter_comp_iter(gt));
+      float amb = k[n_keep - 1].response;
+      auto e = std::partition(k.begin() + n_keep, k.end(), [amb](const RI& a) { return a.response >= amb; });
+      k.resize(e - k.begin());
+    }
+  }
+  for (size_t i = 0; i < k.size(); i++) out_idx[i] = k[i].idx;
+  return (int)k.size();
+}
+
 static void orb_level_sizes(int w, int h, int nlevels, std::vector<Lvl>& L) {
   L.resize(nlevels);
   double sf = (double)1.2f;

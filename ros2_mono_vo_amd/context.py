@@ -81,6 +81,14 @@ class Context:
         self._check(self._L.mvo_orb_detect(self._h, ptr(img), w, h, stride, ch, ptr(kps), cap, C.byref(n)))
         return kps[:n.value].copy()
 
+    def retain_best(self, responses, n_keep, depth_limit=-1):
+        """cv::KeyPointsFilter::retainBest on a response array -> original indices of the survivors, OpenCV order."""
+        r = np.ascontiguousarray(responses, np.float32)
+        out = np.zeros(max(len(r), 1), np.int32)
+        n = C.c_int(0)
+        self._check(self._L.mvo_retain_best(self._h, ptr(r), len(r), int(n_keep), int(depth_limit), ptr(out), C.byref(n)))
+        return out[:n.value].copy()
+
     def fast9_nms(self, img, threshold=20, cap=1 << 20):
         img, w, h, stride, ch = self._img(img)
         assert ch == 1

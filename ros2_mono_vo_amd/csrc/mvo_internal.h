@@ -111,6 +111,12 @@ struct OrbState {
   u8* d_cl = nullptr;      // level of each candidate
   int* d_cslot = nullptr;  // slot of each candidate
   float* d_ch = nullptr;   // harris
+  // retainBest on the device (orb_select.hip): (response, index) pairs + two staging buffers, all cand_cap wide
+  uint2* d_wk = nullptr;
+  uint2* d_stl = nullptr;
+  uint2* d_str = nullptr;
+  int* d_kept = nullptr;     // [B][8] survivors per (slot, level)
+  int* d_kp_base = nullptr;  // [B+1] first selected key-point of each slot in the dense selection
   // final key-points
   int kp_cap = 0;  // dense, whole batch
   int* d_sel = nullptr;  // selected candidate indices
@@ -120,10 +126,7 @@ struct OrbState {
   char4* d_pattern = nullptr;
   int* d_umax = nullptr;
   // pinned host mirrors
-  int* h_counts = nullptr;  // [B][8] + [B+1]
-  u8* h_cs = nullptr;
-  float* h_ch = nullptr;
-  int* h_sel = nullptr;
+  int* h_counts = nullptr;  // [B][8] level counts + [B+1] candidate bases + [B+1] key-point bases
   mvo_keypoint* h_kp = nullptr;
   u8* h_desc = nullptr;
   hipEvent_t ev_counts = nullptr, ev_cand = nullptr;  // phase boundaries of the split detect (orb_detect_enqueue / orb_select)
@@ -185,14 +188,16 @@ int lk_build_pyramid(mvo_ctx* ctx, int set, const LkLevels& L, int nslots, hipSt
 int lk_track_device(mvo_ctx* ctx, int prev_set, int cur_set, const LkLevels& L, int nslots, int max_n, hipStream_t st = nullptr);
 // ORB in three phases on ctx->stream so that a caller can put other GPU work beside the host-side selection:
 //   orb_detect_enqueue  pyramid, FAST+NMS, ordered compaction, async copy of the counts           (no host wait)
-//   orb_select          waits for the counts, Harris + candidate copy (+ the blurred pyramid, which does not depend
-//                       on the selection), then OpenCV's retainBest passes on the host; uploads the selection
+//   orb_select          waits for the counts (capacity check, grid size), Harris, OpenCV's two retainBest passes per
+//                       level on the device, then the blurred pyramid; returns once the per-slot key-point counts are
+//                       on the host (the blur is still running)
 //   orb_describe_enqueue  IC angle + rBRIEF for the selection; `to_host` also copies key-points/descriptors back and waits
 // orb_run is the three in a row.
 int orb_detect_enqueue(mvo_ctx* ctx, int w, int h, int nslots);
 int orb_select(mvo_ctx* ctx, int w, int h, int nslots, bool describe, std::vector<int>& kp_base);
 int orb_describe_enqueue(mvo_ctx* ctx, int w, int h, int nslots, bool describe, bool to_host, const std::vector<int>& kp_base);
 int orb_run(mvo_ctx* ctx, int w, int h, int nslots, bool describe, std::vector<int>& kp_base);
+int orb_select_device(mvo_ctx* ctx, const OrbGeom& G, int nslots);  // orb_select.hip: both retainBest passes + dense gather
 int match_device(mvo_ctx* ctx, int nslots, int max_nq, double ratio);
 int geom_ransac_h(mvo_ctx* ctx, int nslots, const float* p1, const float* p2, const int* d_n, double thr, int max_iters, double conf,
                   u8* mask, double* model, int* result, hipStream_t st);

@@ -617,6 +617,11 @@ int orb_state_create(mvo_ctx* ctx) {
   MVO_HIP(hipMalloc(&o->d_cl, cap));
   MVO_HIP(hipMalloc(&o->d_cslot, cap * sizeof(int)));
   MVO_HIP(hipMalloc(&o->d_ch, cap * sizeof(float)));
+  MVO_HIP(hipMalloc(&o->d_wk, cap * sizeof(uint2)));
+  MVO_HIP(hipMalloc(&o->d_stl, cap * sizeof(uint2)));
+  MVO_HIP(hipMalloc(&o->d_str, cap * sizeof(uint2)));
+  MVO_HIP(hipMalloc(&o->d_kept, (size_t)ctx->B * MVO_ORB_LEVELS * sizeof(int)));
+  MVO_HIP(hipMalloc(&o->d_kp_base, (size_t)(ctx->B + 1) * sizeof(int)));
   o->kp_cap = ctx->maxpts * ctx->B;
   MVO_HIP(hipMalloc(&o->d_sel, (size_t)o->kp_cap * sizeof(int)));
   MVO_HIP(hipMalloc(&o->d_kp, (size_t)o->kp_cap * sizeof(mvo_keypoint)));
@@ -641,10 +646,7 @@ int orb_state_create(mvo_ctx* ctx) {
     }
     MVO_HIP(hipMemcpy(o->d_umax, umax, sizeof(umax), hipMemcpyHostToDevice));
   }
-  MVO_HIP(hipHostMalloc(&o->h_counts, (size_t)(ctx->B * (MVO_ORB_LEVELS + 2) + 1) * sizeof(int), hipHostMallocDefault));
-  MVO_HIP(hipHostMalloc(&o->h_cs, cap, hipHostMallocDefault));
-  MVO_HIP(hipHostMalloc(&o->h_ch, cap * sizeof(float), hipHostMallocDefault));
-  MVO_HIP(hipHostMalloc(&o->h_sel, (size_t)o->kp_cap * sizeof(int), hipHostMallocDefault));
+  MVO_HIP(hipHostMalloc(&o->h_counts, (size_t)(ctx->B * (MVO_ORB_LEVELS + 2) + 2) * sizeof(int), hipHostMallocDefault));
   MVO_HIP(hipHostMalloc(&o->h_kp, (size_t)o->kp_cap * sizeof(mvo_keypoint), hipHostMallocDefault));
   MVO_HIP(hipHostMalloc(&o->h_desc, (size_t)o->kp_cap * 32, hipHostMallocDefault));
   MVO_HIP(hipEventCreateWithFlags(&o->ev_counts, hipEventDisableTiming));
@@ -657,9 +659,9 @@ void orb_state_destroy(mvo_ctx* ctx) {
   if (!o) return;
   void* dev[] = {o->d_pyr, o->d_score, o->d_blur, o->d_row_cnt, o->d_row_off, o->d_lvl_cnt, o->d_slot_tot,
                  o->d_slot_base, o->d_cx, o->d_cy, o->d_cs, o->d_cl, o->d_cslot, o->d_ch, o->d_sel, o->d_kp,
-                 o->d_desc, o->d_pattern, o->d_umax};
+                 o->d_desc, o->d_pattern, o->d_umax, o->d_wk, o->d_stl, o->d_str, o->d_kept, o->d_kp_base};
   for (void* p : dev) (void)hipFree(p);
-  void* hst[] = {o->h_counts, o->h_cs, o->h_ch, o->h_sel, o->h_kp, o->h_desc};
+  void* hst[] = {o->h_counts, o->h_kp, o->h_desc};
   for (void* p : hst)
     if (p) (void)hipHostFree(p);
   if (o->ev_counts) (void)hipEventDestroy(o->ev_counts);
@@ -667,21 +669,6 @@ void orb_state_destroy(mvo_ctx* ctx) {
   delete o;
   ctx->orb = nullptr;
 }
-
-namespace {
-struct RespIdx { float response; int idx; };
-// KeyPointsFilter::retainBest (features2d/src/keypoint.cpp) on (response, index) pairs.
-void retain_best(std::vector<RespIdx>& k, int n) {
-  if (n >= 0 && k.size() > (size_t)n) {
-    if (n == 0) { k.clear(); return; }
-    std::nth_element(k.begin(), k.begin() + n - 1, k.end(),
-                     [](const RespIdx& a, const RespIdx& b) { return a.response > b.response; });
-    float amb = k[n - 1].response;
-    auto e = std::partition(k.begin() + n, k.end(), [amb](const RespIdx& a) { return a.response >= amb; });
-    k.resize(e - k.begin());
-  }
-}
-}  // namespace
 
 // Stage 1 (device): pyramid (level 0 must already be resident in d_pyr), FAST, NMS, compaction, Harris.
 static int orb_detect_device(mvo_ctx* ctx, const OrbGeom& G, int nslots) {
@@ -750,68 +737,34 @@ static void orb_blur_enqueue(mvo_ctx* ctx, const OrbGeom& G, int nslots) {
   }
 }
 
-// Phase 2.  kp_base[s]..kp_base[s+1] is slot s's range in the dense selection (d_sel / h_sel).
+// Phase 2.  kp_base[s]..kp_base[s+1] is slot s's range in the dense selection (d_sel).
 int orb_select(mvo_ctx* ctx, int w, int h, int nslots, bool describe, std::vector<int>& kp_base) {
   OrbState* o = ctx->orb;
   hipStream_t st = ctx->stream;
   OrbGeom G;
   orb_geom_for(ctx, w, h, G);
   MVO_HIP(hipEventSynchronize(o->ev_counts));
-  const int* lvl = o->h_counts;
   const int* sbase = o->h_counts + (size_t)nslots * MVO_ORB_LEVELS;
   int total = sbase[nslots];
   if (total > o->cand_cap) { ctx->set_error("ORB candidate capacity exceeded"); return MVO_E_CAPACITY; }
   kp_base.assign(nslots + 1, 0);
   if (total == 0) return MVO_OK;
-  hipLaunchKernelGGL(harris_kernel, dim3((total + 255) / 256), dim3(256), 0, st, o->d_pyr, G, o->d_cx, o->d_cy, o->d_cl,
-                     o->d_cslot, o->d_slot_base, nslots, o->d_ch, o->cand_cap);
-  MVO_HIP(hipMemcpyAsync(o->h_cs, o->d_cs, (size_t)total, hipMemcpyDeviceToHost, st));
-  MVO_HIP(hipMemcpyAsync(o->h_ch, o->d_ch, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, st));
+  int* h_kpb = o->h_counts + (size_t)nslots * MVO_ORB_LEVELS + nslots + 1;
+  {
+    ProfScope ps(ctx, "orb_select");
+    hipLaunchKernelGGL(harris_kernel, dim3((total + 255) / 256), dim3(256), 0, st, o->d_pyr, G, o->d_cx, o->d_cy, o->d_cl,
+                       o->d_cslot, o->d_slot_base, nslots, o->d_ch, o->cand_cap);
+    // OpenCV's two retainBest passes per level (2*quota by FAST score, quota by Harris), in libstdc++'s element order
+    int rc = orb_select_device(ctx, G, nslots);
+    if (rc) return rc;
+  }
+  MVO_HIP(hipMemcpyAsync(h_kpb, o->d_kp_base, (size_t)(nslots + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
   MVO_HIP(hipEventRecord(o->ev_cand, st));
-  // the blurred pyramid does not depend on the selection: it runs on the device while the host selects
+  // the blurred pyramid does not depend on the selection: queue it before waiting for the counts
   if (describe) { ProfScope ps(ctx, "orb_blur"); orb_blur_enqueue(ctx, G, nslots); }
   MVO_HIP(hipEventSynchronize(o->ev_cand));
-  // ---- host: OpenCV's two retainBest passes per level, on responses only ---------------------------
-  // Streams are independent, so the per-slot selections run on a few host threads; the selected candidate
-  // indices are then concatenated in slot order.
-  std::vector<std::vector<int>> picked(nslots);
-  auto select_slot = [&](int s) {
-    std::vector<RespIdx> k;
-    std::vector<int>& out = picked[s];
-    int off = sbase[s];
-    for (int l = 0; l < G.nlevels; l++) {
-      int cnt = lvl[s * MVO_ORB_LEVELS + l];
-      k.resize(cnt);
-      for (int i = 0; i < cnt; i++) k[i] = {(float)o->h_cs[off + i], off + i};
-      retain_best(k, 2 * G.quota[l]);
-      for (auto& e : k) e.response = o->h_ch[e.idx];
-      retain_best(k, G.quota[l]);
-      for (auto& e : k) out.push_back(e.idx);
-      off += cnt;
-    }
-  };
-  {
-    int nthreads = (int)std::min<size_t>({(size_t)nslots, (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)16});
-    if (nthreads <= 1) {
-      for (int s = 0; s < nslots; s++) select_slot(s);
-    } else {
-      std::atomic<int> next{0};
-      std::vector<std::thread> pool;
-      for (int t = 0; t < nthreads; t++)
-        pool.emplace_back([&]() { for (int s = next.fetch_add(1); s < nslots; s = next.fetch_add(1)) select_slot(s); });
-      for (auto& th : pool) th.join();
-    }
-  }
-  int nsel = 0;
-  for (int s = 0; s < nslots; s++) {
-    kp_base[s] = nsel;
-    if (nsel + (int)picked[s].size() > o->kp_cap) { ctx->set_error("ORB key-point capacity exceeded"); return MVO_E_CAPACITY; }
-    memcpy(o->h_sel + nsel, picked[s].data(), picked[s].size() * sizeof(int));
-    nsel += (int)picked[s].size();
-  }
-  kp_base[nslots] = nsel;
-  if (nsel == 0) return MVO_OK;
-  MVO_HIP(hipMemcpyAsync(o->d_sel, o->h_sel, (size_t)nsel * sizeof(int), hipMemcpyHostToDevice, st));
+  for (int s = 0; s <= nslots; s++) kp_base[s] = h_kpb[s];
+  if (kp_base[nslots] > o->kp_cap) { ctx->set_error("ORB key-point capacity exceeded"); return MVO_E_CAPACITY; }
   return MVO_OK;
 }
 

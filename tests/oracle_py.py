@@ -77,6 +77,13 @@ def fast9_nms(img, thr=20, cap=1 << 20):
     return buf[:min(n, cap)].copy()
 
 
+def retain_best(resp, n_keep, depth_limit=-1):
+    r = np.ascontiguousarray(resp, np.float32)
+    out = np.zeros(max(len(r), 1), np.int32)
+    n = lib().orc_retain_best(_p(r), len(r), int(n_keep), int(depth_limit), _p(out))
+    return out[:n].copy()
+
+
 def orb_level_info(w, h, nfeatures):
     lw = np.zeros(8, np.int32); lh = np.zeros(8, np.int32)
     sc = np.zeros(8, np.float32); q = np.zeros(8, np.int32)

@@ -49,6 +49,45 @@ def test_fast_edge_cases(ctx720):
     assert np.array_equal(ctx720.fast9_nms(noise, 60), O.fast9_nms(noise, 60))
 
 
+def _retain_cases():
+    rng = np.random.default_rng(11)
+    for n in (0, 1, 2, 3, 4, 5, 7, 17, 64, 255, 256, 257, 1000, 5000, 23456):
+        gens = {
+            "u8": lambda: rng.integers(20, 120, n).astype(np.float32),          # FAST scores: heavy ties
+            "float": lambda: rng.normal(0, 1e-3, n).astype(np.float32),          # Harris-like, signed
+            "equal": lambda: np.full(n, 7.0, np.float32),
+            "asc": lambda: np.arange(n, dtype=np.float32),
+            "desc": lambda: np.arange(n, dtype=np.float32)[::-1].copy(),
+            "pipe": lambda: np.concatenate([np.arange(n // 2), np.arange(n - n // 2)[::-1]]).astype(np.float32),
+            "two": lambda: rng.integers(0, 2, n).astype(np.float32),
+        }
+        for name, g in gens.items():
+            r = g()
+            for keep in sorted({0, 1, 2, n // 3, n // 2, max(n - 1, 0), n, n + 5}):
+                yield name, r, keep
+
+
+def test_retain_best_order_bitexact(ctx720):
+    """KeyPointsFilter::retainBest: same survivors in the same ORDER as libstdc++'s nth_element + partition."""
+    cases = 0
+    for name, r, keep in _retain_cases():
+        g = ctx720.retain_best(r, keep)
+        o = O.retain_best(r, keep)
+        assert np.array_equal(g, o), (name, len(r), keep)
+        cases += 1
+    assert cases > 500
+
+
+def test_retain_best_heap_select_branch(ctx720):
+    """introselect's depth-limit branch (__heap_select + iter_swap), forced through the depth_limit test hook."""
+    rng = np.random.default_rng(12)
+    for n in (5, 33, 500, 4097):
+        for r in (rng.integers(0, 50, n).astype(np.float32), rng.normal(0, 1, n).astype(np.float32)):
+            for keep in (1, 2, n // 4, n // 2, n - 2):
+                for depth in (0, 1, 2, 5):
+                    assert np.array_equal(ctx720.retain_best(r, keep, depth), O.retain_best(r, keep, depth)), (n, keep, depth)
+
+
 def _check_orb(ctx, img, nfeat):
     gk, gd = ctx.orb_detect_and_compute(img)
     ok, od = O.orb_detect_and_compute(img, nfeat)

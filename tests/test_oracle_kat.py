@@ -250,3 +250,18 @@ def test_triangulation_recovers_planted_points():
     P2 = K @ np.hstack([sc["R"], sc["t"][:, None]])
     X3, X4 = O.triangulate(P1, P2, sc["p1"], sc["p2"])
     assert np.median(np.abs(X3 - sc["X"]) / np.abs(sc["X"]).max(1, keepdims=True)) < 5e-3   # float32 pixels, 0.3 m baseline
+
+
+def test_retain_best_known_answers():
+    """KeyPointsFilter::retainBest semantics: keeps the n best plus everything tied with the n-th; n >= size is a no-op."""
+    assert list(O.retain_best([1, 5, 3], 1)) == [1]
+    assert sorted(O.retain_best([2, 2, 2, 2], 2)) == [0, 1, 2, 3]
+    assert list(O.retain_best([4, 1, 3], 3)) == [0, 1, 2]
+    assert list(O.retain_best([4, 1, 3], 7)) == [0, 1, 2]
+    assert len(O.retain_best([4, 1, 3], 0)) == 0
+    r = np.array([9, 1, 8, 2, 7, 3, 7, 4], np.float32)
+    got = O.retain_best(r, 3)
+    assert sorted(r[got], reverse=True) == [9, 8, 7, 7]          # tie with the 3rd best is kept
+    # the depth-limit hook only changes the order, never the set
+    for d in (0, 1, 3):
+        assert sorted(O.retain_best(r, 3, d)) == sorted(got)
