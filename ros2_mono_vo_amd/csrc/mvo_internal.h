@@ -111,6 +111,11 @@ struct OrbState {
   u8* d_cl = nullptr;      // level of each candidate
   int* d_cslot = nullptr;  // slot of each candidate
   float* d_ch = nullptr;   // harris
+  // INTER_LINEAR_EXACT coordinate tables of the current frame geometry (offset | c1 << 16 per destination column / row)
+  unsigned* d_rtab = nullptr;
+  size_t rtab_cap = 0;
+  int rtab_x[MVO_ORB_LEVELS] = {0}, rtab_y[MVO_ORB_LEVELS] = {0};
+  int rtab_w = 0, rtab_h = 0;
   // retainBest on the device (orb_select.hip): (response, index) pairs + two staging buffers, all cand_cap wide
   uint2* d_wk = nullptr;
   uint2* d_stl = nullptr;

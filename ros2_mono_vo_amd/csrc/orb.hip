@@ -67,59 +67,74 @@ static void orb_geometry(int w, int h, int nfeatures, int edge, OrbGeom& G) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// resize INTER_LINEAR_EXACT (one level from the previous one)
+// resize INTER_LINEAR_EXACT (one level from the previous one), table driven
 // ---------------------------------------------------------------------------------------------------
-struct LinAxis {
-  double scale;  // 1 / ((double)dst / src)
-  int src, dst;
-};
-
-// Returns offset and 8-bit coefficient c1 (c0 = 256 - c1); edge = -1 (use src[0]) / +1 (use src[last]) / 0.
-__device__ __forceinline__ void lin_coef(const LinAxis a, int v, int& ofs, int& c1, int& edge) {
-  double fval = a.scale * ((double)v + 0.5) - 0.5;
-  int ival = d_cv_floor(fval);
-  edge = 0; ofs = 0; c1 = 0;
-  if (ival >= 0 && a.src > 1) {
-    if (ival < a.src - 1) {
-      ofs = ival;
-      c1 = d_cv_round((fval - (double)ival) * 256.0);
-    } else {
-      ofs = a.src - 1;
-      edge = 1;
-    }
-  } else {
-    edge = -1;
+// OpenCV (resize.cpp, resize_bitExact / interpolationLinear) maps destination coordinate v to
+//   fval = scale * (v + 0.5) - 0.5,  ival = floor(fval),  c1 = round((fval - ival) * 256), c0 = 256 - c1
+// with scale = 1 / ((double)dst / src), clamps to the first / last source sample outside [0, src-1), accumulates
+// the horizontal pass in 8.8 fixed point and rounds the vertical pass as (v + 2^15) >> 16 (rows that clamp:
+// (h + 128) >> 8, which is the same expression with weights (256, 0)).  The coordinate arithmetic is per
+// axis and per level only, so the host tabulates it once per geometry: entry = offset | c1 << 16 with the clamps
+// folded into (offset, c1) pairs that keep offset + 1 inside the source.
+static void lin_table(int src, int dst, std::vector<unsigned>& tab) {
+  const double scale = 1.0 / ((double)dst / src);
+  tab.resize(dst);
+  for (int v = 0; v < dst; v++) {
+    double fval = scale * ((double)v + 0.5) - 0.5;
+    int ival = (int)std::floor(fval);
+    int ofs, c1;
+    if (ival >= 0 && src > 1) {
+      if (ival < src - 1) { ofs = ival; c1 = (int)std::lrint((fval - (double)ival) * 256.0); }
+      else { ofs = src - 2; c1 = 256; }        // right clamp: src[last] << 8
+    } else { ofs = 0; c1 = 0; }                // left clamp (or a 1-sample source): src[0] << 8
+    if (src == 1) { ofs = 0; c1 = 0; }
+    tab[v] = (unsigned)ofs | ((unsigned)c1 << 16);
   }
 }
 
-// OpenCV marks [0, mn) and [mx, dst) as clamped where mn = max(v+1 | left-clamped v) and
-// mx = min(v | right-clamped v); the coordinate map is monotone, so "v is clamped" is equivalent.
-__global__ __launch_bounds__(256) void resize_exact_kernel(const u8* __restrict__ pyr, size_t slot_stride,
-                                                           size_t soff, int spitch, size_t doff, int dpitch,
-                                                           LinAxis ax, LinAxis ay) {
-  int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= ax.dst || y >= ay.dst) return;
+#define RZ_W 64
+#define RZ_H 16
+#define RZ_SP 96   // source tile pitch: 64 * 1.2 + taps + alignment slack (host checks the geometry fits)
+#define RZ_SH 24
+
+__global__ __launch_bounds__(256) void resize_exact_kernel(const u8* __restrict__ pyr, size_t slot_stride, size_t soff, int spitch,
+                                                           size_t doff, int dpitch, int dw, int dh, const unsigned* __restrict__ xtab,
+                                                           const unsigned* __restrict__ ytab) {
+  __shared__ unsigned s_src[RZ_SH * RZ_SP / 4];
   const u8* sp = pyr + (size_t)blockIdx.z * slot_stride + soff;
   u8* dp = const_cast<u8*>(pyr) + (size_t)blockIdx.z * slot_stride + doff;
-  int ox, cx1, ex, oy, cy1, ey;
-  lin_coef(ax, x, ox, cx1, ex);
-  lin_coef(ay, y, oy, cy1, ey);
-  auto hval = [&](int sy) -> unsigned {
-    const u8* r = sp + (size_t)sy * spitch;
-    if (ex < 0) return (unsigned)r[0] << 8;
-    if (ex > 0) return (unsigned)r[ax.src - 1] << 8;
-    return (unsigned)(256 - cx1) * r[ox] + (unsigned)cx1 * r[ox + 1];
-  };
-  unsigned out;
-  if (ey != 0) {
-    unsigned v = hval(ey < 0 ? 0 : ay.src - 1);
-    out = min(255u, (v + 128u) >> 8);
-  } else {
-    unsigned v = hval(oy) * (unsigned)(256 - cy1) + hval(oy + 1) * (unsigned)cy1;
-    out = min(255u, (v + 32768u) >> 16);
+  const int x0 = blockIdx.x * RZ_W, y0 = blockIdx.y * RZ_H, tid = threadIdx.x;
+  const int x1 = min(x0 + RZ_W, dw) - 1, y1 = min(y0 + RZ_H, dh) - 1;
+  const int sxa = (int)(xtab[x0] & 0xFFFFu) & ~3;           // tile origin, dword aligned
+  const int sxe = (int)(xtab[x1] & 0xFFFFu) + 2;            // one past the last source column needed
+  const int sy0 = (int)(ytab[y0] & 0xFFFFu), sy1 = (int)(ytab[y1] & 0xFFFFu) + 1;
+  const int ndw = (sxe - sxa + 3) >> 2, nrow = sy1 - sy0 + 1;
+  for (int i = tid; i < nrow * ndw; i += 256) {
+    int ty = i / ndw, k = i - ty * ndw;
+    s_src[ty * (RZ_SP / 4) + k] = *(const unsigned*)(sp + (size_t)(sy0 + ty) * spitch + sxa + 4 * k);
   }
-  dp[(size_t)y * dpitch + x] = (u8)out;
+  __syncthreads();
+  // 4 horizontally adjacent outputs per lane, one dword store
+  const int row = tid >> 4, c4 = (tid & 15) * 4;
+  const int y = y0 + row, x = x0 + c4;
+  if (y >= dh || x >= dw) return;
+  const unsigned ye = ytab[y];
+  const int cy1 = (int)(ye >> 16), cy0 = 256 - cy1;
+  const u8* r0 = (const u8*)s_src + ((int)(ye & 0xFFFFu) - sy0) * RZ_SP - sxa;
+  const u8* r1 = r0 + RZ_SP;
+  unsigned out = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if (x + j < dw) {
+      const unsigned xe = xtab[x + j];
+      const int ox = (int)(xe & 0xFFFFu), cx1 = (int)(xe >> 16), cx0 = 256 - cx1;
+      unsigned h0 = (unsigned)cx0 * r0[ox] + (unsigned)cx1 * r0[ox + 1];
+      unsigned h1 = (unsigned)cx0 * r1[ox] + (unsigned)cx1 * r1[ox + 1];
+      unsigned v = h0 * (unsigned)cy0 + h1 * (unsigned)cy1;
+      out |= min(255u, (v + 32768u) >> 16) << (8 * j);
+    }
+  }
+  *(unsigned*)(dp + (size_t)y * dpitch + x) = out;  // x % 4 == 0 and pitch % 64 == 0: the padding columns take zeros
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -617,6 +632,8 @@ int orb_state_create(mvo_ctx* ctx) {
   MVO_HIP(hipMalloc(&o->d_cl, cap));
   MVO_HIP(hipMalloc(&o->d_cslot, cap * sizeof(int)));
   MVO_HIP(hipMalloc(&o->d_ch, cap * sizeof(float)));
+  o->rtab_cap = (size_t)(ctx->maxw + ctx->maxh + 64) * MVO_ORB_LEVELS;
+  MVO_HIP(hipMalloc(&o->d_rtab, o->rtab_cap * sizeof(unsigned)));
   MVO_HIP(hipMalloc(&o->d_wk, cap * sizeof(uint2)));
   MVO_HIP(hipMalloc(&o->d_stl, cap * sizeof(uint2)));
   MVO_HIP(hipMalloc(&o->d_str, cap * sizeof(uint2)));
@@ -659,7 +676,7 @@ void orb_state_destroy(mvo_ctx* ctx) {
   if (!o) return;
   void* dev[] = {o->d_pyr, o->d_score, o->d_blur, o->d_row_cnt, o->d_row_off, o->d_lvl_cnt, o->d_slot_tot,
                  o->d_slot_base, o->d_cx, o->d_cy, o->d_cs, o->d_cl, o->d_cslot, o->d_ch, o->d_sel, o->d_kp,
-                 o->d_desc, o->d_pattern, o->d_umax, o->d_wk, o->d_stl, o->d_str, o->d_kept, o->d_kp_base};
+                 o->d_desc, o->d_pattern, o->d_umax, o->d_wk, o->d_stl, o->d_str, o->d_kept, o->d_kp_base, o->d_rtab};
   for (void* p : dev) (void)hipFree(p);
   void* hst[] = {o->h_counts, o->h_kp, o->h_desc};
   for (void* p : hst)
@@ -670,17 +687,48 @@ void orb_state_destroy(mvo_ctx* ctx) {
   ctx->orb = nullptr;
 }
 
+// (Re)build the per-level resize tables when the frame geometry changes.
+static int orb_resize_tables(mvo_ctx* ctx, const OrbGeom& G) {
+  OrbState* o = ctx->orb;
+  if (o->rtab_w == G.w[0] && o->rtab_h == G.h[0]) return MVO_OK;
+  std::vector<unsigned> all, t;
+  for (int l = 1; l < G.nlevels; l++) {
+    lin_table(G.w[l - 1], G.w[l], t);
+    o->rtab_x[l] = (int)all.size();
+    all.insert(all.end(), t.begin(), t.end());
+    // a 64-wide destination tile must fit the LDS source tile
+    for (int x0 = 0; x0 < G.w[l]; x0 += RZ_W) {
+      int x1 = std::min(x0 + RZ_W, G.w[l]) - 1;
+      int span = (int)(t[x1] & 0xFFFFu) + 2 - ((int)(t[x0] & 0xFFFFu) & ~3);
+      if (span > RZ_SP) { ctx->set_error("ORB resize: source tile wider than the LDS tile"); return MVO_E_ARG; }
+    }
+    lin_table(G.h[l - 1], G.h[l], t);
+    o->rtab_y[l] = (int)all.size();
+    all.insert(all.end(), t.begin(), t.end());
+    for (int y0 = 0; y0 < G.h[l]; y0 += RZ_H) {
+      int y1 = std::min(y0 + RZ_H, G.h[l]) - 1;
+      int span = (int)(t[y1] & 0xFFFFu) + 2 - (int)(t[y0] & 0xFFFFu);
+      if (span > RZ_SH) { ctx->set_error("ORB resize: source tile taller than the LDS tile"); return MVO_E_ARG; }
+    }
+  }
+  if (all.size() > o->rtab_cap) { ctx->set_error("ORB resize tables exceed their capacity"); return MVO_E_CAPACITY; }
+  // the previous tables may still be in use by queued kernels
+  MVO_HIP(hipStreamSynchronize(ctx->stream));
+  MVO_HIP(hipMemcpy(o->d_rtab, all.data(), all.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+  o->rtab_w = G.w[0]; o->rtab_h = G.h[0];
+  return MVO_OK;
+}
+
 // Stage 1 (device): pyramid (level 0 must already be resident in d_pyr), FAST, NMS, compaction, Harris.
 static int orb_detect_device(mvo_ctx* ctx, const OrbGeom& G, int nslots) {
   OrbState* o = ctx->orb;
   hipStream_t st = ctx->stream;
+  int rc = orb_resize_tables(ctx, G);
+  if (rc) return rc;
   for (int l = 1; l < G.nlevels; l++) {
-    LinAxis ax, ay;
-    ax.src = G.w[l - 1]; ax.dst = G.w[l]; ax.scale = 1.0 / ((double)G.w[l] / G.w[l - 1]);
-    ay.src = G.h[l - 1]; ay.dst = G.h[l]; ay.scale = 1.0 / ((double)G.h[l] / G.h[l - 1]);
-    dim3 grid((G.w[l] + 63) / 64, (G.h[l] + 3) / 4, nslots);
+    dim3 grid((G.w[l] + RZ_W - 1) / RZ_W, (G.h[l] + RZ_H - 1) / RZ_H, nslots);
     hipLaunchKernelGGL(resize_exact_kernel, grid, dim3(256), 0, st, o->d_pyr, G.slot_stride, G.off[l - 1], G.pitch[l - 1],
-                       G.off[l], G.pitch[l], ax, ay);
+                       G.off[l], G.pitch[l], G.w[l], G.h[l], o->d_rtab + o->rtab_x[l], o->d_rtab + o->rtab_y[l]);
   }
   for (int l = 0; l < G.nlevels; l++) {
     dim3 grid((G.w[l] + FT_W - 1) / FT_W, (G.h[l] + FT_H - 1) / FT_H, nslots);
