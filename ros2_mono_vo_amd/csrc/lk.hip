@@ -23,12 +23,14 @@
 #define PD_SW (2 * PD_TW + 3)
 #define PD_SH (2 * PD_TH + 3)
 
-__global__ __launch_bounds__(256) void pyrdown_kernel(ImgSet src, ImgSet dst) {
+__global__ __launch_bounds__(256) void pyrdown_kernel(ImgSet src, ImgSet dst, TileGrid tg) {
   __shared__ u8 s_src[PD_SH][PD_SW + 1];
   __shared__ unsigned short s_h[PD_SH][PD_TW];
-  const u8* sp = src.slot(blockIdx.z);
-  u8* dp = dst.slot(blockIdx.z);
-  int dx0 = blockIdx.x * PD_TW, dy0 = blockIdx.y * PD_TH;
+  int bx, by, bz;
+  if (!xcd_tile(tg, bx, by, bz)) return;
+  const u8* sp = src.slot(bz);
+  u8* dp = dst.slot(bz);
+  int dx0 = bx * PD_TW, dy0 = by * PD_TH;
   int sx0 = 2 * dx0 - 2, sy0 = 2 * dy0 - 2;
   for (int i = threadIdx.x; i < PD_SH * PD_SW; i += 256) {
     int ty = i / PD_SW, tx = i - ty * PD_SW;
@@ -54,8 +56,8 @@ __global__ __launch_bounds__(256) void pyrdown_kernel(ImgSet src, ImgSet dst) {
 }
 
 static void launch_pyrdown(mvo_ctx* ctx, const ImgSet& s, const ImgSet& d, int nslots, hipStream_t st) {
-  dim3 grid((d.w + PD_TW - 1) / PD_TW, (d.h + PD_TH - 1) / PD_TH, nslots);
-  hipLaunchKernelGGL(pyrdown_kernel, grid, dim3(256), 0, st, s, d);
+  TileGrid tg{(d.w + PD_TW - 1) / PD_TW, (d.h + PD_TH - 1) / PD_TH, nslots};
+  hipLaunchKernelGGL(pyrdown_kernel, dim3(xcd_grid_blocks(tg)), dim3(256), 0, st, s, d, tg);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -228,6 +228,27 @@ __device__ __forceinline__ int d_reflect101(int p, int len) {
   } while ((unsigned)p >= (unsigned)len);
   return p;
 }
+// XCD-aware tile order for the image kernels.  Workgroups are handed to the 8 XCDs round-robin by linear id, and
+// each XCD has its own L2, so with a plain (x, y, slot) grid the tiles that share 128-byte lines and halo rows land
+// on different L2s and every line is fetched from HBM several times (measured 4x the algorithmic bytes).  Here the
+// launch is 1-D and workgroup b works on tile (b % 8) * ceil(n / 8) + b / 8: each XCD walks one contiguous run of
+// tiles (whole images), so neighbours hit in its L2.  Placement is a speed hint only; any mapping is correct.
+struct TileGrid { int gx, gy, gz; };
+static inline unsigned xcd_grid_blocks(const TileGrid& g) {
+  unsigned n = (unsigned)g.gx * g.gy * g.gz;
+  return ((n + 7) / 8) * 8;
+}
+__device__ __forceinline__ bool xcd_tile(const TileGrid& g, int& tx, int& ty, int& tz) {
+  const unsigned n = (unsigned)g.gx * g.gy * g.gz, per = (n + 7) / 8;
+  const unsigned b = blockIdx.x;
+  const unsigned t = (b & 7u) * per + (b >> 3);
+  if (t >= n) return false;
+  const unsigned row = t / g.gx;
+  tx = (int)(t - row * g.gx);
+  tz = (int)(row / g.gy);
+  ty = (int)(row - (unsigned)tz * g.gy);
+  return true;
+}
 __device__ __forceinline__ int d_cv_round(float v) { return __float2int_rn(v); }
 __device__ __forceinline__ int d_cv_round(double v) { return __double2int_rn(v); }
 __device__ __forceinline__ int d_cv_floor(float v) { return (int)floorf(v); }

@@ -93,48 +93,75 @@ static void lin_table(int src, int dst, std::vector<unsigned>& tab) {
 }
 
 #define RZ_W 64
-#define RZ_H 16
+#define RZ_H 32
 #define RZ_SP 96   // source tile pitch: 64 * 1.2 + taps + alignment slack (host checks the geometry fits)
-#define RZ_SH 24
+#define RZ_SH 42   // 32 * 1.2 + taps + slack
+
+// first source sample of destination coordinate v (the table's offset field, recomputed so that the tile loads do not
+// have to wait for a table load): same IEEE double expression as lin_table
+__device__ __forceinline__ int lin_ofs(double scale, int src, int v) {
+  double fval = scale * ((double)v + 0.5) - 0.5;
+  int ival = d_cv_floor(fval);
+  if (ival >= 0 && src > 1) return ival < src - 1 ? ival : src - 2;
+  return 0;
+}
 
 __global__ __launch_bounds__(256) void resize_exact_kernel(const u8* __restrict__ pyr, size_t slot_stride, size_t soff, int spitch,
-                                                           size_t doff, int dpitch, int dw, int dh, const unsigned* __restrict__ xtab,
-                                                           const unsigned* __restrict__ ytab) {
+                                                           int sw, int sh, size_t doff, int dpitch, int dw, int dh, double scale_x,
+                                                           double scale_y, const unsigned* __restrict__ xtab,
+                                                           const unsigned* __restrict__ ytab, TileGrid tg) {
   __shared__ unsigned s_src[RZ_SH * RZ_SP / 4];
-  const u8* sp = pyr + (size_t)blockIdx.z * slot_stride + soff;
-  u8* dp = const_cast<u8*>(pyr) + (size_t)blockIdx.z * slot_stride + doff;
-  const int x0 = blockIdx.x * RZ_W, y0 = blockIdx.y * RZ_H, tid = threadIdx.x;
+  int bx, by, bz;
+  if (!xcd_tile(tg, bx, by, bz)) return;
+  const u8* sp = pyr + (size_t)bz * slot_stride + soff;
+  u8* dp = const_cast<u8*>(pyr) + (size_t)bz * slot_stride + doff;
+  const int x0 = bx * RZ_W, y0 = by * RZ_H, tid = threadIdx.x;
   const int x1 = min(x0 + RZ_W, dw) - 1, y1 = min(y0 + RZ_H, dh) - 1;
-  const int sxa = (int)(xtab[x0] & 0xFFFFu) & ~3;           // tile origin, dword aligned
-  const int sxe = (int)(xtab[x1] & 0xFFFFu) + 2;            // one past the last source column needed
-  const int sy0 = (int)(ytab[y0] & 0xFFFFu), sy1 = (int)(ytab[y1] & 0xFFFFu) + 1;
+  const int sxa = lin_ofs(scale_x, sw, x0) & ~3;           // tile origin, dword aligned
+  const int sxe = lin_ofs(scale_x, sw, x1) + 2;            // one past the last source column needed
+  const int sy0 = lin_ofs(scale_y, sh, y0), sy1 = lin_ofs(scale_y, sh, y1) + 1;
   const int ndw = (sxe - sxa + 3) >> 2, nrow = sy1 - sy0 + 1;
-  for (int i = tid; i < nrow * ndw; i += 256) {
-    int ty = i / ndw, k = i - ty * ndw;
-    s_src[ty * (RZ_SP / 4) + k] = *(const unsigned*)(sp + (size_t)(sy0 + ty) * spitch + sxa + 4 * k);
+  // 4 horizontally adjacent outputs on 2 rows (row, row + 16) per lane; table entries requested before the tile
+  const int row = tid >> 4, c4 = (tid & 15) * 4;
+  const int x = x0 + c4;
+  const bool live = x < dw;
+  uint4 xe = make_uint4(0, 0, 0, 0);
+  if (live) xe = *(const uint4*)(xtab + x);               // tables are padded to a multiple of 4 entries
+  unsigned ye[2];
+#pragma unroll
+  for (int q = 0; q < 2; q++) { int y = y0 + row + 16 * q; ye[q] = (live && y < dh) ? ytab[y] : 0u; }
+  {
+    // 32 lanes per tile row (24 dwords at most), 8 rows per pass: no division, 32-bit multiplies kept off the path
+    // (v_mul_lo_u32 / v_mad_u64_u32 are quarter rate on CDNA)
+    const int k = tid & 31;
+    const u8* gp = sp + (size_t)__umul24(sy0 + (tid >> 5), spitch) + sxa + 4 * k;
+    unsigned* lp = s_src + __umul24(tid >> 5, RZ_SP / 4) + k;
+    if (k < ndw)
+      for (int ty = tid >> 5; ty < nrow; ty += 8, gp += 8 * (size_t)spitch, lp += 8 * (RZ_SP / 4)) *lp = *(const unsigned*)gp;
   }
   __syncthreads();
-  // 4 horizontally adjacent outputs per lane, one dword store
-  const int row = tid >> 4, c4 = (tid & 15) * 4;
-  const int y = y0 + row, x = x0 + c4;
-  if (y >= dh || x >= dw) return;
-  const unsigned ye = ytab[y];
-  const int cy1 = (int)(ye >> 16), cy0 = 256 - cy1;
-  const u8* r0 = (const u8*)s_src + ((int)(ye & 0xFFFFu) - sy0) * RZ_SP - sxa;
-  const u8* r1 = r0 + RZ_SP;
-  unsigned out = 0;
+  if (!live) return;
+  const unsigned xes[4] = {xe.x, xe.y, xe.z, xe.w};
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    if (x + j < dw) {
-      const unsigned xe = xtab[x + j];
-      const int ox = (int)(xe & 0xFFFFu), cx1 = (int)(xe >> 16), cx0 = 256 - cx1;
-      unsigned h0 = (unsigned)cx0 * r0[ox] + (unsigned)cx1 * r0[ox + 1];
-      unsigned h1 = (unsigned)cx0 * r1[ox] + (unsigned)cx1 * r1[ox + 1];
-      unsigned v = h0 * (unsigned)cy0 + h1 * (unsigned)cy1;
-      out |= min(255u, (v + 32768u) >> 16) << (8 * j);
+  for (int q = 0; q < 2; q++) {
+    const int y = y0 + row + 16 * q;
+    if (y >= dh) break;
+    const unsigned cy1 = ye[q] >> 16, cy0 = 256u - cy1;
+    const u8* r0 = (const u8*)s_src + __umul24((ye[q] & 0xFFFFu) - sy0, RZ_SP) - sxa;
+    const u8* r1 = r0 + RZ_SP;
+    unsigned out = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (x + j < dw) {
+        const unsigned ox = xes[j] & 0xFFFFu, cx1 = xes[j] >> 16, cx0 = 256u - cx1;
+        unsigned h0 = __umul24(cx0, r0[ox]) + __umul24(cx1, r0[ox + 1]);   // < 2^16
+        unsigned h1 = __umul24(cx0, r1[ox]) + __umul24(cx1, r1[ox + 1]);
+        unsigned v = __umul24(h0, cy0) + __umul24(h1, cy1);
+        out |= min(255u, (v + 32768u) >> 16) << (8 * j);
+      }
     }
+    *(unsigned*)(dp + (size_t)__umul24(y, dpitch) + x) = out;  // x % 4 == 0 and pitch % 64 == 0: the padding columns take zeros
   }
-  *(unsigned*)(dp + (size_t)y * dpitch + x) = out;  // x % 4 == 0 and pitch % 64 == 0: the padding columns take zeros
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -197,14 +224,16 @@ __device__ __forceinline__ int fast_score_px(const u8* c, int t) {
 // `lo`: scores are only needed for x in [lo, w-lo), y in [lo, h-lo) (lo = max(3, edge-1): NMS of the rows/cols the
 // compaction scans needs one ring of neighbours; everything else is written as 0).
 __global__ __launch_bounds__(256) void fast_nms_kernel(const u8* __restrict__ pyr, u8* __restrict__ score, size_t slot_stride, size_t off,
-                                                       int w, int h, int pitch, int threshold, int lo) {
+                                                       int w, int h, int pitch, int threshold, int lo, TileGrid tg) {
   __shared__ u8 s_px[FT_PH * FT_P];
   __shared__ u8 s_sc[FT_SH * FT_SP];
   __shared__ unsigned short s_list[FT_SH * FT_SW];
   __shared__ int s_n;
-  const u8* sp = pyr + (size_t)blockIdx.z * slot_stride + off;
-  u8* dp = score + (size_t)blockIdx.z * slot_stride + off;
-  const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
+  int bx, by, bz;
+  if (!xcd_tile(tg, bx, by, bz)) return;
+  const u8* sp = pyr + (size_t)bz * slot_stride + off;
+  u8* dp = score + (size_t)bz * slot_stride + off;
+  const int x0 = bx * FT_W, y0 = by * FT_H;
   const int tid = threadIdx.x, lane = tid & 63;
   if (tid == 0) s_n = 0;
   // tiles that cannot contain a needed score: write zeros and leave
@@ -496,12 +525,14 @@ typedef unsigned short bl_ushort2 __attribute__((ext_vector_type(2)));
 // Separable 7-tap blur, all-integer: horizontal taps by v_alignbyte + 2 x v_dot4_u32_u8 per pixel (4 pixels per lane),
 // row sums (<= 257*255, fit u16) stored transposed in LDS, vertical taps by 4 x v_dot2_u32_u16, (s + 2^15) >> 16.
 __global__ __launch_bounds__(256) void blur7_kernel(const u8* __restrict__ pyr, u8* __restrict__ out, size_t slot_stride,
-                                                    size_t off, int w, int h, int pitch, BlurTaps T) {
+                                                    size_t off, int w, int h, int pitch, BlurTaps T, TileGrid tg) {
   __shared__ unsigned s_src[(BL_H + 6) * BL_SP / 4];
   __shared__ unsigned short s_h[BL_W * BL_HP];
-  const u8* sp = pyr + (size_t)blockIdx.z * slot_stride + off;
-  u8* dp = out + (size_t)blockIdx.z * slot_stride + off;
-  const int x0 = blockIdx.x * BL_W, y0 = blockIdx.y * BL_H;
+  int bx, by, bz;
+  if (!xcd_tile(tg, bx, by, bz)) return;
+  const u8* sp = pyr + (size_t)bz * slot_stride + off;
+  u8* dp = out + (size_t)bz * slot_stride + off;
+  const int x0 = bx * BL_W, y0 = by * BL_H;
   const int tid = threadIdx.x;
   // ---- stage 1: source tile rows y0-3 .. y0+18, bytes x0-4 .. x0+67 ---------------------------------------
   const bool interior = x0 >= 4 && x0 + 68 <= w && y0 >= 3 && y0 + BL_H + 3 <= h;
@@ -632,7 +663,7 @@ int orb_state_create(mvo_ctx* ctx) {
   MVO_HIP(hipMalloc(&o->d_cl, cap));
   MVO_HIP(hipMalloc(&o->d_cslot, cap * sizeof(int)));
   MVO_HIP(hipMalloc(&o->d_ch, cap * sizeof(float)));
-  o->rtab_cap = (size_t)(ctx->maxw + ctx->maxh + 64) * MVO_ORB_LEVELS;
+  o->rtab_cap = (size_t)(ctx->maxw + ctx->maxh + 72) * MVO_ORB_LEVELS;
   MVO_HIP(hipMalloc(&o->d_rtab, o->rtab_cap * sizeof(unsigned)));
   MVO_HIP(hipMalloc(&o->d_wk, cap * sizeof(uint2)));
   MVO_HIP(hipMalloc(&o->d_stl, cap * sizeof(uint2)));
@@ -694,8 +725,10 @@ static int orb_resize_tables(mvo_ctx* ctx, const OrbGeom& G) {
   std::vector<unsigned> all, t;
   for (int l = 1; l < G.nlevels; l++) {
     lin_table(G.w[l - 1], G.w[l], t);
+    while (all.size() & 3) all.push_back(0);  // 16-byte aligned: the kernel fetches 4 entries per load
     o->rtab_x[l] = (int)all.size();
     all.insert(all.end(), t.begin(), t.end());
+    while (all.size() & 3) all.push_back(0);
     // a 64-wide destination tile must fit the LDS source tile
     for (int x0 = 0; x0 < G.w[l]; x0 += RZ_W) {
       int x1 = std::min(x0 + RZ_W, G.w[l]) - 1;
@@ -726,14 +759,15 @@ static int orb_detect_device(mvo_ctx* ctx, const OrbGeom& G, int nslots) {
   int rc = orb_resize_tables(ctx, G);
   if (rc) return rc;
   for (int l = 1; l < G.nlevels; l++) {
-    dim3 grid((G.w[l] + RZ_W - 1) / RZ_W, (G.h[l] + RZ_H - 1) / RZ_H, nslots);
-    hipLaunchKernelGGL(resize_exact_kernel, grid, dim3(256), 0, st, o->d_pyr, G.slot_stride, G.off[l - 1], G.pitch[l - 1],
-                       G.off[l], G.pitch[l], G.w[l], G.h[l], o->d_rtab + o->rtab_x[l], o->d_rtab + o->rtab_y[l]);
+    TileGrid tg{(G.w[l] + RZ_W - 1) / RZ_W, (G.h[l] + RZ_H - 1) / RZ_H, nslots};
+    hipLaunchKernelGGL(resize_exact_kernel, dim3(xcd_grid_blocks(tg)), dim3(256), 0, st, o->d_pyr, G.slot_stride, G.off[l - 1],
+                       G.pitch[l - 1], G.w[l - 1], G.h[l - 1], G.off[l], G.pitch[l], G.w[l], G.h[l], 1.0 / ((double)G.w[l] / G.w[l - 1]),
+                       1.0 / ((double)G.h[l] / G.h[l - 1]), o->d_rtab + o->rtab_x[l], o->d_rtab + o->rtab_y[l], tg);
   }
   for (int l = 0; l < G.nlevels; l++) {
-    dim3 grid((G.w[l] + FT_W - 1) / FT_W, (G.h[l] + FT_H - 1) / FT_H, nslots);
-    hipLaunchKernelGGL(fast_nms_kernel, grid, dim3(256), 0, st, o->d_pyr, o->d_score, G.slot_stride, G.off[l], G.w[l],
-                       G.h[l], G.pitch[l], ctx->cfg.fast_threshold, std::max(3, G.edge - 1));
+    TileGrid tg{(G.w[l] + FT_W - 1) / FT_W, (G.h[l] + FT_H - 1) / FT_H, nslots};
+    hipLaunchKernelGGL(fast_nms_kernel, dim3(xcd_grid_blocks(tg)), dim3(256), 0, st, o->d_pyr, o->d_score, G.slot_stride, G.off[l], G.w[l],
+                       G.h[l], G.pitch[l], ctx->cfg.fast_threshold, std::max(3, G.edge - 1), tg);
   }
   int nrows = G.row0[G.nlevels];
   if (nrows > 0) {
@@ -779,9 +813,9 @@ static void orb_blur_enqueue(mvo_ctx* ctx, const OrbGeom& G, int nslots) {
   static const int k1[7] = {18, 34, 48, 56, 48, 34, 18};
   for (int i = 0; i < 7; i++) T.k[i] = ctx->cfg.orb_blur_mode ? k1[i] : k0[i];
   for (int l = 0; l < G.nlevels; l++) {
-    dim3 grid((G.w[l] + BL_W - 1) / BL_W, (G.h[l] + BL_H - 1) / BL_H, nslots);
-    hipLaunchKernelGGL(blur7_kernel, grid, dim3(256), 0, ctx->stream, o->d_pyr, o->d_blur, G.slot_stride, G.off[l], G.w[l], G.h[l],
-                       G.pitch[l], T);
+    TileGrid tg{(G.w[l] + BL_W - 1) / BL_W, (G.h[l] + BL_H - 1) / BL_H, nslots};
+    hipLaunchKernelGGL(blur7_kernel, dim3(xcd_grid_blocks(tg)), dim3(256), 0, ctx->stream, o->d_pyr, o->d_blur, G.slot_stride, G.off[l],
+                       G.w[l], G.h[l], G.pitch[l], T, tg);
   }
 }
 
@@ -896,9 +930,9 @@ extern "C" int mvo_fast9_nms(mvo_ctx* ctx, const uint8_t* img, int w, int h, int
   G.nlevels = 1;
   G.row0[1] = (h <= 6 || w <= 6) ? 0 : h - 6;
   for (int l = 2; l <= MVO_ORB_LEVELS; l++) G.row0[l] = G.row0[1];
-  dim3 grid((w + FT_W - 1) / FT_W, (h + FT_H - 1) / FT_H, 1);
-  hipLaunchKernelGGL(fast_nms_kernel, grid, dim3(256), 0, st, o->d_pyr, o->d_score, G.slot_stride, G.off[0], w, h, G.pitch[0],
-                     threshold, 3);
+  TileGrid tg{(w + FT_W - 1) / FT_W, (h + FT_H - 1) / FT_H, 1};
+  hipLaunchKernelGGL(fast_nms_kernel, dim3(xcd_grid_blocks(tg)), dim3(256), 0, st, o->d_pyr, o->d_score, G.slot_stride, G.off[0], w, h,
+                     G.pitch[0], threshold, 3, tg);
   int nrows = G.row0[1];
   dim3 g2((nrows + 3) / 4, 1);
   hipLaunchKernelGGL(nms_rows_kernel<0>, g2, dim3(256), 0, st, o->d_score, G, o->d_row_cnt, o->d_row_off, o->d_slot_base,
