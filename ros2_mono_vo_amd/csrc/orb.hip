@@ -9,7 +9,6 @@
 //                         wavefront per image row, 4 pixels per lane, __ballot + popcount: pass 0 counts, pass 1 emits
 //   scan_rows/scan_slots  exclusive scans (rows -> levels -> slots) so candidates of the whole batch are
 //                         one dense array
-//   harris_kernel         7x7 Harris response of every candidate (int sums, f32 response)
 //   [host]                KeyPointsFilter::retainBest twice per level with libstdc++ nth_element/partition
 //                         on the response arrays only: that permutation IS OpenCV's key-point order
 //   ic_angle_kernel       intensity-centroid orientation, one wavefront per key-point, exact int moments
@@ -408,38 +407,6 @@ __global__ void scan_slots_kernel(const int* __restrict__ slot_tot, int* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Harris response (orb.cpp HarrisResponses, blockSize 7, k 0.04)
-// ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void harris_kernel(const u8* __restrict__ pyr, OrbGeom G,
-                                                     const unsigned short* __restrict__ cx,
-                                                     const unsigned short* __restrict__ cy, const u8* __restrict__ cl,
-                                                     const int* __restrict__ cslot, const int* __restrict__ slot_base,
-                                                     int nslots, float* __restrict__ ch, int cand_cap) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  int total = min(slot_base[nslots], cand_cap);
-  if (i >= total) return;
-  int l = cl[i], x0 = cx[i], y0 = cy[i];
-  const int pitch = G.pitch[l];
-  const u8* img = pyr + (size_t)cslot[i] * G.slot_stride + G.off[l];
-  int a = 0, b = 0, c = 0;
-  // candidates are >= 31 px inside the level, so the 9x9 footprint never leaves it
-  for (int dy = -3; dy <= 3; dy++) {
-    const u8* r0 = img + (size_t)(y0 + dy - 1) * pitch + x0;
-    const u8* r1 = r0 + pitch;
-    const u8* r2 = r1 + pitch;
-#pragma unroll
-    for (int dx = -3; dx <= 3; dx++) {
-      int Ix = (r1[dx + 1] - r1[dx - 1]) * 2 + (r0[dx + 1] - r0[dx - 1]) + (r2[dx + 1] - r2[dx - 1]);
-      int Iy = (r2[dx] - r0[dx]) * 2 + (r2[dx - 1] - r0[dx - 1]) + (r2[dx + 1] - r0[dx + 1]);
-      a += Ix * Ix; b += Iy * Iy; c += Ix * Iy;
-    }
-  }
-  const float scale = 1.f / ((1 << 2) * 7 * 255.f);
-  const float scale_sq_sq = scale * scale * scale * scale;
-  ch[i] = ((float)a * b - (float)c * c - 0.04f * ((float)a + b) * ((float)a + b)) * scale_sq_sq;
-}
-
-// ---------------------------------------------------------------------------------------------------
 // IC angle: one wavefront per selected key-point
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float d_fast_atan2(float y, float x) {
@@ -825,18 +792,13 @@ int orb_select(mvo_ctx* ctx, int w, int h, int nslots, bool describe, std::vecto
   hipStream_t st = ctx->stream;
   OrbGeom G;
   orb_geom_for(ctx, w, h, G);
-  MVO_HIP(hipEventSynchronize(o->ev_counts));
   const int* sbase = o->h_counts + (size_t)nslots * MVO_ORB_LEVELS;
-  int total = sbase[nslots];
-  if (total > o->cand_cap) { ctx->set_error("ORB candidate capacity exceeded"); return MVO_E_CAPACITY; }
   kp_base.assign(nslots + 1, 0);
-  if (total == 0) return MVO_OK;
   int* h_kpb = o->h_counts + (size_t)nslots * MVO_ORB_LEVELS + nslots + 1;
   {
+    // OpenCV's two retainBest passes per level (2*quota by FAST score, quota by Harris), in libstdc++'s element order;
+    // the Harris responses of the first pass's survivors are computed in between, inside the same kernel
     ProfScope ps(ctx, "orb_select");
-    hipLaunchKernelGGL(harris_kernel, dim3((total + 255) / 256), dim3(256), 0, st, o->d_pyr, G, o->d_cx, o->d_cy, o->d_cl,
-                       o->d_cslot, o->d_slot_base, nslots, o->d_ch, o->cand_cap);
-    // OpenCV's two retainBest passes per level (2*quota by FAST score, quota by Harris), in libstdc++'s element order
     int rc = orb_select_device(ctx, G, nslots);
     if (rc) return rc;
   }
@@ -844,7 +806,8 @@ int orb_select(mvo_ctx* ctx, int w, int h, int nslots, bool describe, std::vecto
   MVO_HIP(hipEventRecord(o->ev_cand, st));
   // the blurred pyramid does not depend on the selection: queue it before waiting for the counts
   if (describe) { ProfScope ps(ctx, "orb_blur"); orb_blur_enqueue(ctx, G, nslots); }
-  MVO_HIP(hipEventSynchronize(o->ev_cand));
+  MVO_HIP(hipEventSynchronize(o->ev_cand));  // also covers the candidate counts queued by orb_detect_enqueue
+  if (sbase[nslots] > o->cand_cap) { ctx->set_error("ORB candidate capacity exceeded"); return MVO_E_CAPACITY; }
   for (int s = 0; s <= nslots; s++) kp_base[s] = h_kpb[s];
   if (kp_base[nslots] > o->kp_cap) { ctx->set_error("ORB key-point capacity exceeded"); return MVO_E_CAPACITY; }
   return MVO_OK;

@@ -214,9 +214,44 @@ __device__ int rb_retain_best(uint2* a, int cnt, int n, uint2* stL, uint2* stR, 
 // ---------------------------------------------------------------------------------------------------
 // ORB: both passes for one (stream, level) job
 // ---------------------------------------------------------------------------------------------------
+// Harris response of one candidate (orb.cpp HarrisResponses, blockSize 7, k 0.04): integer sums over the 7x7 block of
+// Sobel-like 3x3 derivatives, i.e. a 9x9 byte footprint, fetched as 9 rows x 3 (unaligned) dwords.  Candidates are
+// >= 31 px inside the level, so the footprint never leaves it.
+__device__ float orb_harris(const u8* __restrict__ img, int pitch, int x0, int y0) {
+  unsigned rw[9][3];
+  const u8* p = img + (size_t)__umul24(y0 - 4, pitch) + x0 - 4;
+#pragma unroll
+  for (int r = 0; r < 9; r++, p += pitch) {
+    const unsigned* q = (const unsigned*)p;  // byte-aligned address: the memory pipeline takes misaligned dwords
+    rw[r][0] = q[0]; rw[r][1] = q[1]; rw[r][2] = q[2];
+  }
+  auto px = [&](int r, int k) -> int { return (int)((rw[r][k >> 2] >> (8 * (k & 3))) & 0xFFu); };  // k = dx + 4
+  int a = 0, b = 0, c = 0;
+#pragma unroll
+  for (int dy = -3; dy <= 3; dy++) {
+    const int r0 = dy + 3, r1 = dy + 4, r2 = dy + 5;
+#pragma unroll
+    for (int dx = -3; dx <= 3; dx++) {
+      const int k = dx + 4;
+      int Ix = (px(r1, k + 1) - px(r1, k - 1)) * 2 + (px(r0, k + 1) - px(r0, k - 1)) + (px(r2, k + 1) - px(r2, k - 1));
+      int Iy = (px(r2, k) - px(r0, k)) * 2 + (px(r2, k - 1) - px(r0, k - 1)) + (px(r2, k + 1) - px(r0, k + 1));
+      a += __mul24(Ix, Ix); b += __mul24(Iy, Iy); c += __mul24(Ix, Iy);
+    }
+  }
+  const float scale = 1.f / ((1 << 2) * 7 * 255.f);
+  const float scale_sq_sq = scale * scale * scale * scale;
+  return ((float)a * b - (float)c * c - 0.04f * ((float)a + b) * ((float)a + b)) * scale_sq_sq;
+}
+
 struct OrbSelArgs {
   const u8* cs;        // FAST score of each candidate (dense, slot-major then level then row-major)
-  const float* ch;     // Harris response of each candidate
+  float* ch;           // Harris response, written for the survivors of the first pass (ic_angle reads it back)
+  const u8* pyr;       // un-blurred pyramid
+  size_t slot_stride;
+  size_t lvl_off[MVO_ORB_LEVELS];
+  int lvl_pitch[MVO_ORB_LEVELS];
+  const unsigned short* cx;
+  const unsigned short* cy;
   const int* lvl_cnt;  // [B][8]
   const int* slot_base;  // [B+1]
   uint2* wk; uint2* stL; uint2* stR;  // [cand_cap] each
@@ -237,7 +272,17 @@ __global__ __launch_bounds__(RB_T) void orb_select_kernel(OrbSelArgs A) {
   for (int i = tid; i < cnt; i += RB_T) a[i] = make_uint2(__float_as_uint((float)A.cs[off + i]), (unsigned)(off + i));
   __syncthreads();
   int m = rb_retain_best(a, cnt, 2 * A.quota[l], A.stL + off, A.stR + off, S, -1);
-  for (int i = tid; i < m; i += RB_T) a[i].x = __float_as_uint(A.ch[a[i].y]);
+  // OpenCV computes the Harris response of the first pass's survivors only (orb.cpp computeKeyPoints)
+  {
+    const u8* img = A.pyr + (size_t)slot * A.slot_stride + A.lvl_off[l];
+    const int pitch = A.lvl_pitch[l];
+    for (int i = tid; i < m; i += RB_T) {
+      const unsigned ci = a[i].y;
+      const float hr = orb_harris(img, pitch, A.cx[ci], A.cy[ci]);
+      A.ch[ci] = hr;
+      a[i].x = __float_as_uint(hr);
+    }
+  }
   __syncthreads();
   m = rb_retain_best(a, m, A.quota[l], A.stL + off, A.stR + off, S, -1);
   if (tid == 0) A.kept[slot * MVO_ORB_LEVELS + l] = m;
@@ -272,6 +317,8 @@ int orb_select_device(mvo_ctx* ctx, const OrbGeom& G, int nslots) {
   OrbState* o = ctx->orb;
   OrbSelArgs A;
   A.cs = o->d_cs; A.ch = o->d_ch; A.lvl_cnt = o->d_lvl_cnt; A.slot_base = o->d_slot_base;
+  A.pyr = o->d_pyr; A.slot_stride = G.slot_stride; A.cx = o->d_cx; A.cy = o->d_cy;
+  for (int l = 0; l < MVO_ORB_LEVELS; l++) { A.lvl_off[l] = G.off[l]; A.lvl_pitch[l] = G.pitch[l]; }
   A.wk = o->d_wk; A.stL = o->d_stl; A.stR = o->d_str; A.kept = o->d_kept;
   A.nlevels = G.nlevels;
   for (int l = 0; l < MVO_ORB_LEVELS; l++) A.quota[l] = G.quota[l];
