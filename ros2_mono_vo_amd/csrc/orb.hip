@@ -167,13 +167,12 @@ __global__ __launch_bounds__(256) void resize_exact_kernel(const u8* __restrict_
 // FAST-9/16 + 3x3 NMS, fused: the output map holds the score of NMS survivors and 0 elsewhere
 // ---------------------------------------------------------------------------------------------------
 #define FT_W 64
-#define FT_H 16
-#define FT_PW (FT_W + 8)   // pixel tile: 1 (NMS halo) + 3 (circle radius) on each side
-#define FT_PH (FT_H + 8)
-#define FT_P 76            // pixel tile pitch (bytes)
-#define FT_SW (FT_W + 2)   // score tile (NMS halo 1)
-#define FT_SH (FT_H + 2)
-#define FT_SP 68           // score tile pitch
+#define FT_H 32
+#define FT_PR (FT_H + 8)   // pixel tile rows: 1 (NMS halo) + 3 (circle radius) on each side
+#define FT_P 76            // tile pitch in bytes; tile column c is image x0 - 4 + c, so 4-pixel groups are dword aligned
+#define FT_PD (FT_P / 4)
+#define FT_SR (FT_H + 2)   // score tile rows (NMS halo 1); same column indexing and pitch as the pixel tile
+#define FT_NG 18           // 4-pixel groups per tile row
 
 __device__ __forceinline__ bool has9(unsigned m) {
   unsigned m2 = m | (m << 16);
@@ -220,82 +219,171 @@ __device__ __forceinline__ int fast_score_px(const u8* c, int t) {
   return max(a0, -b0) - 1;
 }
 
-// `lo`: scores are only needed for x in [lo, w-lo), y in [lo, h-lo) (lo = max(3, edge-1): NMS of the rows/cols the
-// compaction scans needs one ring of neighbours; everything else is written as 0).
-__global__ __launch_bounds__(256) void fast_nms_kernel(const u8* __restrict__ pyr, u8* __restrict__ score, size_t slot_stride, size_t off,
-                                                       int w, int h, int pitch, int threshold, int lo, TileGrid tg) {
-  __shared__ u8 s_px[FT_PH * FT_P];
-  __shared__ u8 s_sc[FT_SH * FT_SP];
-  __shared__ unsigned short s_list[FT_SH * FT_SW];
+typedef unsigned short ft_us2 __attribute__((ext_vector_type(2)));
+typedef short ft_s2 __attribute__((ext_vector_type(2)));
+// bytes (0,1) / (2,3) of a dword as two zero-extended 16-bit lanes (v_perm_b32)
+__device__ __forceinline__ ft_us2 ft_lo(unsigned d) { return __builtin_bit_cast(ft_us2, __builtin_amdgcn_perm(0u, d, 0x0c010c00u)); }
+__device__ __forceinline__ ft_us2 ft_hi(unsigned d) { return __builtin_bit_cast(ft_us2, __builtin_amdgcn_perm(0u, d, 0x0c030c02u)); }
+__device__ __forceinline__ ft_us2 ft_max(ft_us2 a, ft_us2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ ft_us2 ft_min(ft_us2 a, ft_us2 b) { return __builtin_elementwise_min(a, b); }
+
+// sign bits (bit 15 / 31) clear where a pixel passes the 4-point pre-test of FAST-9: a 9-arc on the 16-circle
+// contains one end of each antipodal pair, so a corner needs (p0 or p8) and (p4 or p12) brighter than v + t, or
+// both darker than v - t.  Two pixels per call, packed 16-bit arithmetic.
+__device__ __forceinline__ unsigned ft_pretest2(ft_us2 v, ft_us2 p0, ft_us2 p8, ft_us2 p4, ft_us2 p12, ft_s2 t1) {
+  ft_us2 M = ft_min(ft_max(p0, p8), ft_max(p4, p12));   // bright side: M > v + t
+  ft_us2 m = ft_max(ft_min(p0, p8), ft_min(p4, p12));   // dark side:   m < v - t
+  ft_s2 e = __builtin_bit_cast(ft_s2, M) - __builtin_bit_cast(ft_s2, v) - t1;   // >= 0  <=>  M - v >= t + 1
+  ft_s2 f = __builtin_bit_cast(ft_s2, v) - __builtin_bit_cast(ft_s2, m) - t1;   // >= 0  <=>  v - m >= t + 1
+  return __builtin_bit_cast(unsigned, e) & __builtin_bit_cast(unsigned, f);
+}
+
+struct FastArgs {
+  const u8* pyr; u8* score;
+  size_t slot_stride, off;
+  int w, h, pitch, threshold;
+  int lo;        // scores are only needed for x in [lo, w-lo), y in [lo, h-lo) (lo = max(3, edge-1): the NMS of the rows /
+                 // columns the compaction scans needs one ring of neighbours); everything else is written as 0
+  int edge;      // the compaction scans rows [edge, h-edge) x columns [edge, w-edge): survivors there are counted per row
+  int* row_cnt;  // [slots][max_rows], zeroed before the launch; this level's rows start at row_first
+  int max_rows, row_first;
+  TileGrid tg;
+};
+
+// FAST-9/16 + cornerScore + strict 3x3 NMS for one 64x32 tile, plus the per-row survivor counts of the ordered
+// compaction.  Phase 1 rejects with the 4-point pre-test, 4 pixels per lane from aligned LDS dwords; phase 2 runs the
+// 16-pixel test and cornerScore for the compacted candidates (dense lanes); phase 3 is the NMS, 4 pixels per lane.
+__global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs A) {
+  __shared__ unsigned s_px[FT_PR * FT_PD];
+  __shared__ unsigned s_sc[FT_SR * FT_PD];
+  __shared__ unsigned short s_list[FT_SR * (FT_W + 2) + 64];
   __shared__ int s_n;
   int bx, by, bz;
-  if (!xcd_tile(tg, bx, by, bz)) return;
-  const u8* sp = pyr + (size_t)bz * slot_stride + off;
-  u8* dp = score + (size_t)bz * slot_stride + off;
+  if (!xcd_tile(A.tg, bx, by, bz)) return;
+  const u8* sp = A.pyr + (size_t)bz * A.slot_stride + A.off;
+  u8* dp = A.score + (size_t)bz * A.slot_stride + A.off;
+  const int w = A.w, h = A.h, pitch = A.pitch, lo = A.lo;
   const int x0 = bx * FT_W, y0 = by * FT_H;
   const int tid = threadIdx.x, lane = tid & 63;
-  if (tid == 0) s_n = 0;
   // tiles that cannot contain a needed score: write zeros and leave
   const bool dead = x0 + FT_W + 1 <= lo || x0 - 1 >= w - lo || y0 + FT_H + 1 <= lo || y0 - 1 >= h - lo;
   if (dead) {
-    int row = tid >> 4, c4 = (tid & 15) * 4;
-    if (y0 + row < h && x0 + c4 < pitch) *(unsigned*)(dp + (size_t)(y0 + row) * pitch + x0 + c4) = 0u;
+    const int c4 = (tid & 15) * 4;
+    for (int row = tid >> 4; row < FT_H; row += 16)
+      if (y0 + row < h && x0 + c4 < pitch) *(unsigned*)(dp + (size_t)__umul24(y0 + row, pitch) + x0 + c4) = 0u;
     return;
   }
-  for (int i = tid; i < FT_PH * FT_PW; i += 256) {
-    int ty = i / FT_PW, tx = i - ty * FT_PW;
-    int gx = min(max(x0 - 4 + tx, 0), w - 1), gy = min(max(y0 - 4 + ty, 0), h - 1);
-    s_px[ty * FT_P + tx] = sp[(size_t)gy * pitch + gx];
-  }
-  for (int i = tid; i < FT_SH * FT_SP / 4; i += 256) ((unsigned*)s_sc)[i] = 0u;
-  __syncthreads();
-  // ---- phase 1: antipodal-pair reject (a 9-arc contains one pixel of every antipodal pair) + compaction -----
-  for (int i0 = 0; i0 < FT_SH * FT_SW; i0 += 256) {
-    int i = i0 + tid;
-    bool cand = false;
-    if (i < FT_SH * FT_SW) {
-      int sy = i / FT_SW, sx = i - sy * FT_SW;
-      int gx = x0 - 1 + sx, gy = y0 - 1 + sy;
-      if (gx >= lo && gx < w - lo && gy >= lo && gy < h - lo) {
-        const u8* c = &s_px[(sy + 3) * FT_P + sx + 3];
-        int v = c[0], vb = v + threshold, vd = v - threshold;
-        int p0 = c[3 * FT_P], p8 = c[-3 * FT_P], p4 = c[3], p12 = c[-3];
-        bool br = ((p0 > vb) | (p8 > vb)) & ((p4 > vb) | (p12 > vb));
-        bool dk = ((p0 < vd) | (p8 < vd)) & ((p4 < vd) | (p12 < vd));
-        cand = br | dk;
-      }
+  if (tid == 0) s_n = 0;
+  // ---- phase 0: pixel tile rows y0-4 .. y0+35, columns x0-4 .. x0+67 ----------------------------------------------------
+  const bool interior = x0 >= 4 && x0 + 68 <= w && y0 >= 4 && y0 + FT_H + 4 <= h;
+  if (interior) {
+    const int k = tid & 31;
+    if (k < FT_NG) {
+      const u8* gp = sp + (size_t)__umul24(y0 - 4 + (tid >> 5), pitch) + x0 - 4 + 4 * k;
+      unsigned* lp = s_px + __umul24(tid >> 5, FT_PD) + k;
+      for (int ty = tid >> 5; ty < FT_PR; ty += 8, gp += 8 * (size_t)pitch, lp += 8 * FT_PD) *lp = *(const unsigned*)gp;
     }
-    unsigned long long m = __ballot(cand);
-    int base = 0;
-    if (lane == 0 && m) base = atomicAdd(&s_n, __popcll(m));
-    base = __shfl(base, 0, 64);
-    if (cand) s_list[base + __popcll(m & ((1ull << lane) - 1))] = (unsigned short)i;
+  } else {
+    u8* sb = (u8*)s_px;
+    for (int i = tid; i < FT_PR * 72; i += 256) {
+      int ty = i / 72, tx = i - ty * 72;
+      int gx = min(max(x0 - 4 + tx, 0), w - 1), gy = min(max(y0 - 4 + ty, 0), h - 1);
+      sb[ty * FT_P + tx] = sp[(size_t)__umul24(gy, pitch) + gx];
+    }
   }
+  for (int i = tid; i < FT_SR * FT_PD; i += 256) s_sc[i] = 0u;
   __syncthreads();
-  // ---- phase 2: full 16-pixel test + cornerScore for the survivors only (dense lanes) ---------------------------
-  const int n = s_n;
-  for (int k = tid; k < n; k += 256) {
-    int i = s_list[k];
-    int sy = i / FT_SW, sx = i - sy * FT_SW;
-    int sc = fast_score_px(&s_px[(sy + 3) * FT_P + sx + 3], threshold);
-    s_sc[sy * FT_SP + sx] = (u8)sc;
-  }
-  __syncthreads();
-  // ---- phase 3: strict 3x3 NMS, 4 pixels per lane, one dword store -----------------------------------------------
+  // ---- phase 1: pre-test, 4 pixels per item; item = (score row sy, group g), image y = y0-1+sy, x = x0-4+4g+j ----------
   {
-    int row = tid >> 4, c4 = (tid & 15) * 4;
-    const u8* r1 = &s_sc[(row + 1) * FT_SP + c4 + 1];
-    const u8* r0 = r1 - FT_SP;
-    const u8* r2 = r1 + FT_SP;
-    unsigned out = 0;
+    const ft_s2 t1 = {(short)(A.threshold + 1), (short)(A.threshold + 1)};
+    // columns of this tile that need a score: [x0-1, x0+64] clipped to [lo, w-lo)
+    const int cx_lo = max(x0 - 1, lo), cx_hi = min(x0 + FT_W + 1, w - lo);  // [cx_lo, cx_hi)
+    for (int it0 = 0; it0 < FT_SR * FT_NG; it0 += 256) {
+      const int it = it0 + tid;
+      unsigned cmask = 0;  // bit j: pixel j of the group is a candidate
+      int sy = 0, g = 0;
+      if (it < FT_SR * FT_NG) {
+        sy = it / FT_NG; g = it - sy * FT_NG;
+        const int gy = y0 - 1 + sy, gx = x0 - 4 + 4 * g;
+        if (gy >= lo && gy < h - lo && gx + 3 >= cx_lo && gx < cx_hi) {
+          const unsigned* c = s_px + __umul24(sy + 3, FT_PD) + g;
+          const unsigned Dl = c[-1], Dc = c[0], Dr = c[1], Du = c[-3 * FT_PD], Dd = c[3 * FT_PD];
+          const unsigned P4 = __builtin_amdgcn_alignbyte(Dr, Dc, 3);    // x + 3
+          const unsigned P12 = __builtin_amdgcn_alignbyte(Dc, Dl, 1);   // x - 3
+          unsigned s01 = ft_pretest2(ft_lo(Dc), ft_lo(Dd), ft_lo(Du), ft_lo(P4), ft_lo(P12), t1);
+          unsigned s23 = ft_pretest2(ft_hi(Dc), ft_hi(Dd), ft_hi(Du), ft_hi(P4), ft_hi(P12), t1);
+          cmask = (~s01 >> 15 & 1u) | (~s01 >> 30 & 2u) | (~s23 >> 13 & 4u) | (~s23 >> 28 & 8u);
+          // clip to the needed columns
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      int sv = r1[j];
-      bool keep = sv && sv > r1[j - 1] && sv > r1[j + 1] && sv > r0[j - 1] && sv > r0[j] && sv > r0[j + 1] && sv > r2[j - 1] &&
-                  sv > r2[j] && sv > r2[j + 1];
-      out |= keep ? ((unsigned)sv << (8 * j)) : 0u;
+          for (int j = 0; j < 4; j++)
+            if (gx + j < cx_lo || gx + j >= cx_hi) cmask &= ~(1u << j);
+        }
+      }
+      // one LDS atomic per wave and pass; the order of the list does not matter
+      const unsigned long long m0 = __ballot(cmask & 1u), m1 = __ballot(cmask & 2u), m2 = __ballot(cmask & 4u), m3 = __ballot(cmask & 8u);
+      const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
+      int base = 0;
+      if (lane == 0 && (n0 + n1 + n2 + n3)) base = atomicAdd(&s_n, n0 + n1 + n2 + n3);
+      base = __shfl(base, 0, 64);
+      const unsigned long long below = (1ull << lane) - 1;
+      const unsigned code = (unsigned)(sy << 7) | (unsigned)(4 * g);
+      if (cmask & 1u) s_list[base + __popcll(m0 & below)] = (unsigned short)(code);
+      if (cmask & 2u) s_list[base + n0 + __popcll(m1 & below)] = (unsigned short)(code + 1);
+      if (cmask & 4u) s_list[base + n0 + n1 + __popcll(m2 & below)] = (unsigned short)(code + 2);
+      if (cmask & 8u) s_list[base + n0 + n1 + n2 + __popcll(m3 & below)] = (unsigned short)(code + 3);
     }
-    if (y0 + row < h && x0 + c4 < pitch) *(unsigned*)(dp + (size_t)(y0 + row) * pitch + x0 + c4) = out;
+  }
+  __syncthreads();
+  // ---- phase 2: full 16-pixel test + cornerScore for the candidates only (dense lanes) -----------------------------------
+  {
+    const int n = s_n;
+    const u8* pb = (const u8*)s_px;
+    u8* sb = (u8*)s_sc;
+    for (int k = tid; k < n; k += 256) {
+      const int code = s_list[k];
+      const int sy = code >> 7, c = code & 127;
+      const int sc = fast_score_px(pb + __umul24(sy + 3, FT_P) + c, A.threshold);
+      sb[__umul24(sy, FT_P) + c] = (u8)sc;
+    }
+  }
+  __syncthreads();
+  // ---- phase 3: strict 3x3 NMS, 4 pixels per item, one dword store; per-row survivor counts ----------------------------
+  for (int it = tid; it < FT_H * 16; it += 256) {
+    const int r = it >> 4, g = (it & 15) + 1;
+    const int gy = y0 + r, gx = x0 + 4 * (g - 1);
+    const unsigned* c = s_sc + __umul24(r + 1, FT_PD) + g;
+    ft_us2 nlo, nhi;  // running maximum of the 8 neighbours
+    {
+      const unsigned L = c[-1], C = c[0], R = c[1];
+      const unsigned a = __builtin_amdgcn_alignbyte(C, L, 3), b = __builtin_amdgcn_alignbyte(R, C, 1);
+      nlo = ft_max(ft_lo(a), ft_lo(b)); nhi = ft_max(ft_hi(a), ft_hi(b));
+    }
+#pragma unroll
+    for (int q = -1; q <= 1; q += 2) {
+      const unsigned L = c[q * FT_PD - 1], C = c[q * FT_PD], R = c[q * FT_PD + 1];
+      const unsigned a = __builtin_amdgcn_alignbyte(C, L, 3), b = __builtin_amdgcn_alignbyte(R, C, 1);
+      nlo = ft_max(nlo, ft_max(ft_lo(C), ft_max(ft_lo(a), ft_lo(b))));
+      nhi = ft_max(nhi, ft_max(ft_hi(C), ft_max(ft_hi(a), ft_hi(b))));
+    }
+    const unsigned C1 = c[0];
+    const ft_s2 vlo = __builtin_bit_cast(ft_s2, ft_lo(C1)), vhi = __builtin_bit_cast(ft_s2, ft_hi(C1));
+    // keep where v > max(neighbours): (max - v) negative; v > max >= 0 also makes v non-zero
+    const ft_s2 klo = (__builtin_bit_cast(ft_s2, nlo) - vlo) >> 15, khi = (__builtin_bit_cast(ft_s2, nhi) - vhi) >> 15;
+    const unsigned olo = __builtin_bit_cast(unsigned, vlo) & __builtin_bit_cast(unsigned, klo);
+    const unsigned ohi = __builtin_bit_cast(unsigned, vhi) & __builtin_bit_cast(unsigned, khi);
+    const unsigned out = __builtin_amdgcn_perm(ohi, olo, 0x06040200u);
+    if (gy < h && gx < pitch) *(unsigned*)(dp + (size_t)__umul24(gy, pitch) + gx) = out;
+    // survivors inside the compaction band, summed over the 16 lanes that share this row
+    int cnt = 0;
+    if (gy >= A.edge && gy < h - A.edge) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) cnt += ((out >> (8 * j)) & 0xFFu) != 0 && gx + j >= A.edge && gx + j < w - A.edge;
+    }
+    cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x111, 0xf, 0xf, true);  // row_shr:1
+    cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x112, 0xf, 0xf, true);  // row_shr:2
+    cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x114, 0xf, 0xf, true);  // row_shr:4
+    cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x118, 0xf, 0xf, true);  // row_shr:8
+    if ((tid & 15) == 15 && cnt > 0) atomicAdd(A.row_cnt + (size_t)bz * A.max_rows + A.row_first + (gy - A.edge), cnt);
   }
 }
 
@@ -685,6 +773,18 @@ void orb_state_destroy(mvo_ctx* ctx) {
   ctx->orb = nullptr;
 }
 
+static void fast_nms_launch(mvo_ctx* ctx, const OrbGeom& G, int l, int nslots, int threshold, int lo) {
+  OrbState* o = ctx->orb;
+  FastArgs A;
+  A.pyr = o->d_pyr; A.score = o->d_score; A.slot_stride = G.slot_stride; A.off = G.off[l];
+  A.w = G.w[l]; A.h = G.h[l]; A.pitch = G.pitch[l]; A.threshold = threshold; A.lo = lo;
+  // a level with no compaction rows (smaller than the edge band) must not count anything
+  A.edge = G.row0[l + 1] > G.row0[l] ? G.edge : (1 << 20);
+  A.row_cnt = o->d_row_cnt; A.max_rows = o->max_rows; A.row_first = G.row0[l];
+  A.tg = TileGrid{(G.w[l] + FT_W - 1) / FT_W, (G.h[l] + FT_H - 1) / FT_H, nslots};
+  hipLaunchKernelGGL(fast_nms_kernel, dim3(xcd_grid_blocks(A.tg)), dim3(256), 0, ctx->stream, A);
+}
+
 // (Re)build the per-level resize tables when the frame geometry changes.
 static int orb_resize_tables(mvo_ctx* ctx, const OrbGeom& G) {
   OrbState* o = ctx->orb;
@@ -731,17 +831,10 @@ static int orb_detect_device(mvo_ctx* ctx, const OrbGeom& G, int nslots) {
                        G.pitch[l - 1], G.w[l - 1], G.h[l - 1], G.off[l], G.pitch[l], G.w[l], G.h[l], 1.0 / ((double)G.w[l] / G.w[l - 1]),
                        1.0 / ((double)G.h[l] / G.h[l - 1]), o->d_rtab + o->rtab_x[l], o->d_rtab + o->rtab_y[l], tg);
   }
-  for (int l = 0; l < G.nlevels; l++) {
-    TileGrid tg{(G.w[l] + FT_W - 1) / FT_W, (G.h[l] + FT_H - 1) / FT_H, nslots};
-    hipLaunchKernelGGL(fast_nms_kernel, dim3(xcd_grid_blocks(tg)), dim3(256), 0, st, o->d_pyr, o->d_score, G.slot_stride, G.off[l], G.w[l],
-                       G.h[l], G.pitch[l], ctx->cfg.fast_threshold, std::max(3, G.edge - 1), tg);
-  }
+  // per-row survivor counts are accumulated by the FAST/NMS kernel itself (phase 3)
+  MVO_HIP(hipMemsetAsync(o->d_row_cnt, 0, (size_t)nslots * o->max_rows * sizeof(int), st));
+  for (int l = 0; l < G.nlevels; l++) fast_nms_launch(ctx, G, l, nslots, ctx->cfg.fast_threshold, std::max(3, G.edge - 1));
   int nrows = G.row0[G.nlevels];
-  if (nrows > 0) {
-    dim3 grid((nrows + 3) / 4, nslots);
-    hipLaunchKernelGGL(nms_rows_kernel<0>, grid, dim3(256), 0, st, o->d_score, G, o->d_row_cnt, o->d_row_off,
-                       o->d_slot_base, o->max_rows, o->d_cx, o->d_cy, o->d_cs, o->d_cl, o->d_cslot, o->cand_cap);
-  }
   hipLaunchKernelGGL(scan_rows_kernel, dim3(nslots), dim3(1024), 0, st, o->d_row_cnt, o->d_row_off, G, o->max_rows,
                      o->d_lvl_cnt, o->d_slot_tot);
   hipLaunchKernelGGL(scan_slots_kernel, dim3(1), dim3(64), 0, st, o->d_slot_tot, o->d_slot_base, nslots);
@@ -893,13 +986,10 @@ extern "C" int mvo_fast9_nms(mvo_ctx* ctx, const uint8_t* img, int w, int h, int
   G.nlevels = 1;
   G.row0[1] = (h <= 6 || w <= 6) ? 0 : h - 6;
   for (int l = 2; l <= MVO_ORB_LEVELS; l++) G.row0[l] = G.row0[1];
-  TileGrid tg{(w + FT_W - 1) / FT_W, (h + FT_H - 1) / FT_H, 1};
-  hipLaunchKernelGGL(fast_nms_kernel, dim3(xcd_grid_blocks(tg)), dim3(256), 0, st, o->d_pyr, o->d_score, G.slot_stride, G.off[0], w, h,
-                     G.pitch[0], threshold, 3, tg);
+  MVO_HIP(hipMemsetAsync(o->d_row_cnt, 0, (size_t)o->max_rows * sizeof(int), st));
+  fast_nms_launch(ctx, G, 0, 1, threshold, 3);
   int nrows = G.row0[1];
   dim3 g2((nrows + 3) / 4, 1);
-  hipLaunchKernelGGL(nms_rows_kernel<0>, g2, dim3(256), 0, st, o->d_score, G, o->d_row_cnt, o->d_row_off, o->d_slot_base,
-                     o->max_rows, o->d_cx, o->d_cy, o->d_cs, o->d_cl, o->d_cslot, o->cand_cap);
   hipLaunchKernelGGL(scan_rows_kernel, dim3(1), dim3(1024), 0, st, o->d_row_cnt, o->d_row_off, G, o->max_rows, o->d_lvl_cnt,
                      o->d_slot_tot);
   hipLaunchKernelGGL(scan_slots_kernel, dim3(1), dim3(64), 0, st, o->d_slot_tot, o->d_slot_base, 1);
