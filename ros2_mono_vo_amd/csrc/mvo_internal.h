@@ -198,7 +198,7 @@ int lk_track_device(mvo_ctx* ctx, int prev_set, int cur_set, const LkLevels& L, 
 //                       on the host (the blur is still running)
 //   orb_describe_enqueue  IC angle + rBRIEF for the selection; `to_host` also copies key-points/descriptors back and waits
 // orb_run is the three in a row.
-int orb_detect_enqueue(mvo_ctx* ctx, int w, int h, int nslots);
+int orb_detect_enqueue(mvo_ctx* ctx, int w, int h, int nslots, hipEvent_t before_fast = nullptr);
 int orb_select(mvo_ctx* ctx, int w, int h, int nslots, bool describe, std::vector<int>& kp_base);
 int orb_describe_enqueue(mvo_ctx* ctx, int w, int h, int nslots, bool describe, bool to_host, const std::vector<int>& kp_base);
 int orb_run(mvo_ctx* ctx, int w, int h, int nslots, bool describe, std::vector<int>& kp_base);

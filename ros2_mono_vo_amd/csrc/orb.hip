@@ -820,7 +820,7 @@ static int orb_resize_tables(mvo_ctx* ctx, const OrbGeom& G) {
 }
 
 // Stage 1 (device): pyramid (level 0 must already be resident in d_pyr), FAST, NMS, compaction, Harris.
-static int orb_detect_device(mvo_ctx* ctx, const OrbGeom& G, int nslots) {
+static int orb_detect_device(mvo_ctx* ctx, const OrbGeom& G, int nslots, hipEvent_t before_fast) {
   OrbState* o = ctx->orb;
   hipStream_t st = ctx->stream;
   int rc = orb_resize_tables(ctx, G);
@@ -831,6 +831,9 @@ static int orb_detect_device(mvo_ctx* ctx, const OrbGeom& G, int nslots) {
                        G.pitch[l - 1], G.w[l - 1], G.h[l - 1], G.off[l], G.pitch[l], G.w[l], G.h[l], 1.0 / ((double)G.w[l] / G.w[l - 1]),
                        1.0 / ((double)G.h[l] / G.h[l - 1]), o->d_rtab + o->rtab_x[l], o->d_rtab + o->rtab_y[l], tg);
   }
+  // The caller may hold the wide FAST kernels back until some other stream's work is through (the pipeline's LK kernel
+  // heads its critical chain and would otherwise share the CUs with FAST half and half).
+  if (before_fast) MVO_HIP(hipStreamWaitEvent(st, before_fast, 0));
   // per-row survivor counts are accumulated by the FAST/NMS kernel itself (phase 3)
   MVO_HIP(hipMemsetAsync(o->d_row_cnt, 0, (size_t)nslots * o->max_rows * sizeof(int), st));
   for (int l = 0; l < G.nlevels; l++) fast_nms_launch(ctx, G, l, nslots, ctx->cfg.fast_threshold, std::max(3, G.edge - 1));
@@ -852,12 +855,12 @@ static void orb_geom_for(mvo_ctx* ctx, int w, int h, OrbGeom& G) {
 }
 
 // Phase 1.  Level 0 of each slot must be resident in orb->d_pyr.  h_counts: [B][8] lvl counts, then [B+1] slot bases.
-int orb_detect_enqueue(mvo_ctx* ctx, int w, int h, int nslots) {
+int orb_detect_enqueue(mvo_ctx* ctx, int w, int h, int nslots, hipEvent_t before_fast) {
   OrbState* o = ctx->orb;
   OrbGeom G;
   orb_geom_for(ctx, w, h, G);
   int rc;
-  { ProfScope ps(ctx, "orb_detect"); rc = orb_detect_device(ctx, G, nslots); }
+  { ProfScope ps(ctx, "orb_detect"); rc = orb_detect_device(ctx, G, nslots, before_fast); }
   if (rc) return rc;
   MVO_HIP(hipMemcpyAsync(o->h_counts, o->d_lvl_cnt, (size_t)nslots * MVO_ORB_LEVELS * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   MVO_HIP(hipMemcpyAsync(o->h_counts + (size_t)nslots * MVO_ORB_LEVELS, o->d_slot_base, (size_t)(nslots + 1) * sizeof(int),

@@ -120,7 +120,7 @@ struct PipeState {
   // side streams: the latency-bound RANSAC chains run beside ORB (they only depend on the LK survivors)
   // s_lk carries pyramid + LK + filter (high priority: the RANSAC chains hang off it), main stream carries ORB.
   hipStream_t s_lk = nullptr, s_pnp = nullptr, s_hf = nullptr;
-  hipEvent_t ev_frame = nullptr, ev_lk = nullptr, ev_pnp = nullptr, ev_hf = nullptr;
+  hipEvent_t ev_frame = nullptr, ev_lktrack = nullptr, ev_lk = nullptr, ev_pnp = nullptr, ev_hf = nullptr;
   int trk_max_n = 0;  // host-side bound on the per-slot track count (grid sizing)
   int kf_max_n = 0;   // host-side bound on the key-frame descriptor count
 };
@@ -160,6 +160,7 @@ int pipe_state_create(mvo_ctx* ctx) {
     MVO_HIP(hipStreamCreateWithFlags(&p->s_hf, hipStreamNonBlocking));
   }
   MVO_HIP(hipEventCreateWithFlags(&p->ev_frame, hipEventDisableTiming));
+  MVO_HIP(hipEventCreateWithFlags(&p->ev_lktrack, hipEventDisableTiming));
   MVO_HIP(hipEventCreateWithFlags(&p->ev_lk, hipEventDisableTiming));
   MVO_HIP(hipEventCreateWithFlags(&p->ev_pnp, hipEventDisableTiming));
   MVO_HIP(hipEventCreateWithFlags(&p->ev_hf, hipEventDisableTiming));
@@ -181,6 +182,7 @@ void pipe_state_destroy(mvo_ctx* ctx) {
     if (p->h_ints) (void)hipHostFree(p->h_ints);
     if (p->s_lk) { (void)hipStreamSynchronize(p->s_lk); (void)hipStreamDestroy(p->s_lk); }
     if (p->ev_frame) (void)hipEventDestroy(p->ev_frame);
+    if (p->ev_lktrack) (void)hipEventDestroy(p->ev_lktrack);
     if (p->s_pnp) { (void)hipStreamSynchronize(p->s_pnp); (void)hipStreamDestroy(p->s_pnp); }
     if (p->s_hf) { (void)hipStreamSynchronize(p->s_hf); (void)hipStreamDestroy(p->s_hf); }
     if (p->ev_lk) (void)hipEventDestroy(p->ev_lk);
@@ -500,7 +502,6 @@ extern "C" int mvo_batch_step(mvo_ctx* ctx, int frame_idx, unsigned stages, mvo_
   if ((rc = pipe_load_frame(ctx, frame_idx, cur_set))) return rc;
   MVO_HIP(hipEventRecord(p->ev_frame, ctx->stream));
   const bool do_orb = stages & MVO_STAGE_ORB;
-  if (do_orb && (rc = orb_detect_enqueue(ctx, p->w, p->h, B))) return rc;
   MVO_HIP(hipStreamWaitEvent(p->s_lk, p->ev_frame, 0));
   { ProfScope ps(ctx, "lk_pyramid", p->s_lk); lk_build_pyramid(ctx, cur_set, L, B, p->s_lk); }
   // pinned layout: hb[0..B) n_prev, [B..2B) n_tracked, [2B..3B) n_matches, [3B..4B) n_tri, [4B..5B) n_new_tracks,
@@ -510,6 +511,10 @@ extern "C" int mvo_batch_step(mvo_ctx* ctx, int frame_idx, unsigned stages, mvo_
   double* hp = g->h_model;
   if (stages & MVO_STAGE_LK) {
     { ProfScope ps(ctx, "lk_track", p->s_lk); lk_track_device(ctx, prev_set, cur_set, L, B, p->trk_max_n, p->s_lk); }
+    MVO_HIP(hipEventRecord(p->ev_lktrack, p->s_lk));
+    // ORB's pyramid runs beside LK; its wide FAST kernels start when LK is through (LK heads the critical chain
+    // LK -> PnP RANSAC -> refine -> triangulate, whose later links leave most of the device to ORB anyway)
+    if (do_orb && (rc = orb_detect_enqueue(ctx, p->w, p->h, B, p->ev_lktrack))) return rc;
     ProfScope ps(ctx, "lk_filter", p->s_lk);
     hipLaunchKernelGGL(lk_filter_compact_kernel, dim3(B), dim3(1024), 0, p->s_lk, ctx->d_next_pts, ctx->d_status, ctx->d_err,
                        ctx->d_npts, p->d_lm, p->d_kf_pts, ctx->cfg.tracking_error_thresh, ctx->maxpts, p->d_cur_pts,
@@ -517,6 +522,7 @@ extern "C" int mvo_batch_step(mvo_ctx* ctx, int frame_idx, unsigned stages, mvo_
     MVO_HIP(hipMemcpyAsync(hb, ctx->d_npts, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, p->s_lk));
     MVO_HIP(hipMemcpyAsync(hb + B, p->d_ncur, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, p->s_lk));
   }
+  if (do_orb && !(stages & MVO_STAGE_LK) && (rc = orb_detect_enqueue(ctx, p->w, p->h, B))) return rc;
   MVO_HIP(hipEventRecord(p->ev_lk, p->s_lk));
   const bool do_pnp = (stages & MVO_STAGE_LK) && (stages & MVO_STAGE_PNP);
   const bool do_hf = (stages & MVO_STAGE_LK) && (stages & MVO_STAGE_HF);
