@@ -46,10 +46,16 @@ struct RansacArgs {
 // of that size on every SIMD of its CU, starving the image kernels (ORB) that run beside it on the main stream.  With
 // one wave per stream a launch occupies one SIMD per stream and scoring is a per-lane loop over uniform point loads.
 #define RS_T 64
+// Register budget: 2 waves per SIMD (<= 256 VGPRs).  The solvers would take up to 420 VGPRs, and one such wave per SIMD
+// pushes the image kernels that share the CU (ORB's FAST runs beside the RANSAC chains) down to 1-2 waves per SIMD;
+// the chains have slack, the main stream does not.
+#ifndef RS_WAVES_PER_EU
+#define RS_WAVES_PER_EU 2
+#endif
 #define RS_NW (RS_T / 64)
 
 template <class M>
-__global__ __launch_bounds__(RS_T) void ransac_kernel(RansacArgs A) {
+__global__ __launch_bounds__(RS_T, RS_WAVES_PER_EU) void ransac_kernel(RansacArgs A) {
   constexpr int RS_CH = M::CH, RS_PARTS = RS_T / RS_CH;
   // per-lane workspace stride: == 1 (mod 32) doubles, so lane-uniform 8-byte accesses of 16 lanes fall into distinct banks
   constexpr int WSS = M::WS > 0 ? ((M::WS + 30) / 32) * 32 + 1 : 1;
@@ -288,6 +294,9 @@ __global__ __launch_bounds__(1024) void mask_to_indices_kernel(const u8* __restr
 // One wavefront per stream: the kernel needs ~500 VGPRs for its 78 double accumulators, and a 4-wave workgroup of
 // that size per stream took every SIMD of the chip for itself (ORB's kernels on the main stream stalled behind it).
 #define PR_T 64
+#ifndef PR_WAVES_PER_EU
+#define PR_WAVES_PER_EU 2
+#endif
 #define PR_NW (PR_T / 64)
 // deterministic block-wide sum of `K` doubles per thread: butterfly inside each wave (every lane ends with the same
 // bits), then the wave partials through LDS in a fixed order.  s_red must hold PR_NW*K doubles.
@@ -325,7 +334,7 @@ struct PnpRefineArgs {
 
 // One workgroup per stream.  Sums over the inlier set are block reductions in a fixed order (the oracle
 // sums sequentially, so R,t agree to rounding, not bit for bit); the small dense solves run on lane 0.
-__global__ __launch_bounds__(PR_T) void pnp_refine_kernel(PnpRefineArgs A) {
+__global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRefineArgs A) {
   __shared__ double s_red[PR_NW * 78];
   __shared__ double s_sh[160];  // broadcast area
   __shared__ double s_mat[2 * 144 + 16];  // lane-0 dense solves work in LDS, not in scratch (latency)
