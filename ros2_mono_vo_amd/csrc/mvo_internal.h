@@ -130,6 +130,7 @@ struct OrbState {
   u8* d_desc = nullptr;
   char4* d_pattern = nullptr;
   int* d_umax = nullptr;
+  unsigned* d_icmask = nullptr;  // [16][9] byte masks of the IC-angle disc rows
   // pinned host mirrors
   int* h_counts = nullptr;  // [B][8] level counts + [B+1] candidate bases + [B+1] key-point bases
   mvo_keypoint* h_kp = nullptr;

@@ -525,35 +525,42 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
   return v;
 }
 
+// Half a wavefront per key-point, one lane per patch row dy = lane - 15.  The lane fetches its row x0-16 .. x0+19 as
+// nine (misaligned) dwords, masks the bytes outside the disc (|u| <= umax[|dy|]; masks tabulated per |dy|) and gets
+// the row sum and the (u + 16)-weighted row sum with two v_dot4_u32_u8 per dword.  Integer moments: any summation
+// order gives OpenCV's m_10 / m_01 (orb.cpp IC_Angle).
 __global__ __launch_bounds__(256) void ic_angle_kernel(const u8* __restrict__ pyr, OrbGeom G, const int* __restrict__ sel,
                                                        int nsel, const unsigned short* __restrict__ cx,
                                                        const unsigned short* __restrict__ cy, const u8* __restrict__ cl,
                                                        const int* __restrict__ cslot, const float* __restrict__ ch,
-                                                       const int* __restrict__ umax, mvo_keypoint* __restrict__ kp) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int k = blockIdx.x * 4 + wave;
-  if (k >= nsel) return;
-  const int ci = sel[k];
-  const int l = cl[ci], x0 = cx[ci], y0 = cy[ci];
-  const int pitch = G.pitch[l];
-  const u8* c = pyr + (size_t)cslot[ci] * G.slot_stride + G.off[l] + (size_t)y0 * pitch + x0;
-  // lanes 0..30 -> u = lane-15 on row +v / centre row; lanes 32..62 -> row -v
-  const int u = (lane & 31) - ORB_HALF;
-  const bool lo = lane < 32;
-  const bool ulane = (lane & 31) < 31;
-  int m10 = 0, m01 = 0;
-  if (lo && ulane) m10 = u * c[u];
-  for (int v = 1; v <= ORB_HALF; v++) {
-    int d = umax[v];
-    if (ulane && u >= -d && u <= d) {
-      int val = lo ? c[u + v * pitch] : c[u - v * pitch];
-      m10 += u * val;
-      m01 += lo ? v * val : -v * val;
+                                                       const unsigned* __restrict__ icmask /* [16][9] */, mvo_keypoint* __restrict__ kp) {
+  const int lane = threadIdx.x & 63, sub = lane & 31;
+  const int k = blockIdx.x * 8 + (threadIdx.x >> 5);
+  const bool live = k < nsel;
+  int m10 = 0, m01 = 0, ci = 0, l = 0, x0 = 0, y0 = 0;
+  if (live) {
+    ci = sel[k];
+    l = cl[ci]; x0 = cx[ci]; y0 = cy[ci];
+    if (sub < 31) {
+      const int dy = sub - ORB_HALF, ady = dy < 0 ? -dy : dy;
+      const int pitch = G.pitch[l];
+      const unsigned* q = (const unsigned*)(pyr + (size_t)cslot[ci] * G.slot_stride + G.off[l] + (size_t)__mul24(y0 + dy, pitch) + x0 - 16);
+      const unsigned* mk = icmask + ady * 9;
+      unsigned rs = 0, ws = 0;
+#pragma unroll
+      for (int j = 0; j < 9; j++) {
+        const unsigned d = q[j] & mk[j];
+        const unsigned wt = (unsigned)(4 * j) * 0x01010101u + 0x03020100u;   // weights u + 16 = byte index 4j .. 4j+3
+        rs = __builtin_amdgcn_udot4(d, 0x01010101u, rs, false);
+        ws = __builtin_amdgcn_udot4(d, wt, ws, false);
+      }
+      m10 = (int)ws - 16 * (int)rs;
+      m01 = dy * (int)rs;
     }
   }
-  m10 = wave_sum_i32(m10);
-  m01 = wave_sum_i32(m01);
-  if (lane == 0) {
+#pragma unroll
+  for (int m = 16; m >= 1; m >>= 1) { m10 += __shfl_xor(m10, m, 64); m01 += __shfl_xor(m01, m, 64); }
+  if (live && sub == 0) {
     float sf = G.scale[l];
     mvo_keypoint o;
     o.x = (float)x0 * sf;
@@ -748,6 +755,19 @@ int orb_state_create(mvo_ctx* ctx) {
       ++v0;
     }
     MVO_HIP(hipMemcpy(o->d_umax, umax, sizeof(umax), hipMemcpyHostToDevice));
+    // IC-angle row masks: row |dy| keeps bytes u + 16 of the 36-byte window x0-16 .. x0+19 with |u| <= umax[|dy|]
+    unsigned icm[16 * 9];
+    for (int v = 0; v < 16; v++)
+      for (int j = 0; j < 9; j++) {
+        unsigned m = 0;
+        for (int b = 0; b < 4; b++) {
+          int u = 4 * j + b - 16;
+          if (u >= -umax[v] && u <= umax[v]) m |= 0xFFu << (8 * b);
+        }
+        icm[v * 9 + j] = m;
+      }
+    MVO_HIP(hipMalloc(&o->d_icmask, sizeof(icm)));
+    MVO_HIP(hipMemcpy(o->d_icmask, icm, sizeof(icm), hipMemcpyHostToDevice));
   }
   MVO_HIP(hipHostMalloc(&o->h_counts, (size_t)(ctx->B * (MVO_ORB_LEVELS + 2) + 2) * sizeof(int), hipHostMallocDefault));
   MVO_HIP(hipHostMalloc(&o->h_kp, (size_t)o->kp_cap * sizeof(mvo_keypoint), hipHostMallocDefault));
@@ -762,7 +782,7 @@ void orb_state_destroy(mvo_ctx* ctx) {
   if (!o) return;
   void* dev[] = {o->d_pyr, o->d_score, o->d_blur, o->d_row_cnt, o->d_row_off, o->d_lvl_cnt, o->d_slot_tot,
                  o->d_slot_base, o->d_cx, o->d_cy, o->d_cs, o->d_cl, o->d_cslot, o->d_ch, o->d_sel, o->d_kp,
-                 o->d_desc, o->d_pattern, o->d_umax, o->d_wk, o->d_stl, o->d_str, o->d_kept, o->d_kp_base, o->d_rtab};
+                 o->d_desc, o->d_pattern, o->d_umax, o->d_wk, o->d_stl, o->d_str, o->d_kept, o->d_kp_base, o->d_rtab, o->d_icmask};
   for (void* p : dev) (void)hipFree(p);
   void* hst[] = {o->h_counts, o->h_kp, o->h_desc};
   for (void* p : hst)
@@ -919,8 +939,8 @@ int orb_describe_enqueue(mvo_ctx* ctx, int w, int h, int nslots, bool describe, 
   if (nsel == 0) return MVO_OK;
   {
     ProfScope ps(ctx, "orb_describe");
-    hipLaunchKernelGGL(ic_angle_kernel, dim3((nsel + 3) / 4), dim3(256), 0, st, o->d_pyr, G, o->d_sel, nsel, o->d_cx, o->d_cy,
-                       o->d_cl, o->d_cslot, o->d_ch, o->d_umax, o->d_kp);
+    hipLaunchKernelGGL(ic_angle_kernel, dim3((nsel + 7) / 8), dim3(256), 0, st, o->d_pyr, G, o->d_sel, nsel, o->d_cx, o->d_cy,
+                       o->d_cl, o->d_cslot, o->d_ch, o->d_icmask, o->d_kp);
     if (describe)
       hipLaunchKernelGGL(brief_kernel, dim3((nsel + 7) / 8), dim3(256), 0, st, o->d_blur, G, o->d_sel, nsel, o->d_cl, o->d_cslot,
                          o->d_kp, o->d_pattern, o->d_desc);
