@@ -649,16 +649,32 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
 // ---------------------------------------------------------------------------------------------------
 // triangulation (one point per lane) and recoverPose
 // ---------------------------------------------------------------------------------------------------
+// cv::triangulatePoints for one correspondence: null vector of the 4x4 DLT matrix = last row of Vt.  The 4x4 Jacobi SVD
+// runs in registers (gl_jacobi_svd_fixed); a rank-deficient system takes the general routine instead.
+__device__ GL_NOINLINE void gm_triangulate_general(const double* A, double X[4]) {
+  double w[4], vt[16], ta[16], tv[16];
+  gl_svd_compute(A, 4, 4, w, nullptr, vt, false, ta, tv);
+  for (int k = 0; k < 4; k++) X[k] = vt[12 + k];
+}
 __device__ inline void gm_triangulate_one(const double* P1, const double* P2, double x1, double y1, double x2, double y2, double X[4]) {
-  double A[16], w[4], vt[16], ta[16], tv[16];
+  double A[16], At[16], W[4], Vt[16];
+#pragma unroll
   for (int k = 0; k < 4; k++) {
     A[0 * 4 + k] = x1 * P1[8 + k] - P1[0 + k];
     A[1 * 4 + k] = y1 * P1[8 + k] - P1[4 + k];
     A[2 * 4 + k] = x2 * P2[8 + k] - P2[0 + k];
     A[3 * 4 + k] = y2 * P2[8 + k] - P2[4 + k];
   }
-  gl_svd_compute(A, 4, 4, w, nullptr, vt, false, ta, tv);
-  for (int k = 0; k < 4; k++) X[k] = vt[12 + k];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) At[j * 4 + i] = A[i * 4 + j];
+  if (gl_jacobi_svd_fixed<4, 4>(At, W, Vt)) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) X[k] = Vt[12 + k];
+  } else {
+    gm_triangulate_general(A, X);
+  }
 }
 
 struct Proj2 { double P1[12], P2[12]; };

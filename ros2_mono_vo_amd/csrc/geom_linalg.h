@@ -237,6 +237,100 @@ __device__ GL_NOINLINE void gl_jacobi_svd(double* At, int astep, double* Wout, d
   }
 }
 
+// JacobiSVDImpl_<double> for compile-time sizes, everything in registers: the same operation sequence as
+// gl_jacobi_svd (every loop unrolled, the data-dependent row swaps of the final sort written as predicated swaps over
+// static indices).  Only the main path: when a singular value is <= DBL_MIN the reference completes the basis with a
+// seeded Gram-Schmidt; that case returns false and the caller re-runs the general routine.
+template <int M, int N>
+__device__ __forceinline__ bool gl_jacobi_svd_fixed(double (&At)[N * M], double (&W)[N], double (&Vt)[N * N]) {
+  const double minval = DBL_MIN, eps = DBL_EPSILON * 10;
+  const int max_iter = M > 30 ? M : 30;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    double sd = 0;
+#pragma unroll
+    for (int k = 0; k < M; k++) { double t = At[i * M + k]; sd += t * t; }
+    W[i] = sd;
+#pragma unroll
+    for (int k = 0; k < N; k++) Vt[i * N + k] = 0;
+    Vt[i * N + i] = 1;
+  }
+  for (int iter = 0; iter < max_iter; iter++) {
+    bool changed = false;
+#pragma unroll
+    for (int i = 0; i < N - 1; i++)
+#pragma unroll
+      for (int j = i + 1; j < N; j++) {
+        double a = W[i], p = 0, b = W[j];
+#pragma unroll
+        for (int k = 0; k < M; k++) p += At[i * M + k] * At[j * M + k];
+        if (fabs(p) <= eps * sqrt(a * b)) continue;
+        p *= 2;
+        double beta = a - b, gamma = gl_hypot(p, beta), c, s;
+        if (beta < 0) {
+          double delta = (gamma - beta) * 0.5;
+          s = sqrt(delta / gamma);
+          c = p / (gamma * s * 2);
+        } else {
+          c = sqrt((gamma + beta) / (gamma * 2));
+          s = p / (gamma * c * 2);
+        }
+        a = b = 0;
+#pragma unroll
+        for (int k = 0; k < M; k++) {
+          double t0 = c * At[i * M + k] + s * At[j * M + k];
+          double t1 = -s * At[i * M + k] + c * At[j * M + k];
+          At[i * M + k] = t0; At[j * M + k] = t1;
+          a += t0 * t0; b += t1 * t1;
+        }
+        W[i] = a; W[j] = b;
+        changed = true;
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+          double t0 = c * Vt[i * N + k] + s * Vt[j * N + k];
+          double t1 = -s * Vt[i * N + k] + c * Vt[j * N + k];
+          Vt[i * N + k] = t0; Vt[j * N + k] = t1;
+        }
+      }
+    if (!changed) break;
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    double sd = 0;
+#pragma unroll
+    for (int k = 0; k < M; k++) { double t = At[i * M + k]; sd += t * t; }
+    W[i] = sqrt(sd);
+  }
+#pragma unroll
+  for (int i = 0; i < N - 1; i++) {
+    int j = i;
+    double wj = W[i];
+#pragma unroll
+    for (int k = i + 1; k < N; k++)
+      if (wj < W[k]) { j = k; wj = W[k]; }
+#pragma unroll
+    for (int q = i + 1; q < N; q++)
+      if (j == q) {
+        gl_swap(W[i], W[q]);
+#pragma unroll
+        for (int k = 0; k < M; k++) gl_swap(At[i * M + k], At[q * M + k]);
+#pragma unroll
+        for (int k = 0; k < N; k++) gl_swap(Vt[i * N + k], Vt[q * N + k]);
+      }
+  }
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < N; i++) ok = ok && W[i] > minval;
+  if (!ok) return false;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    double s = 1 / W[i];
+#pragma unroll
+    for (int k = 0; k < M; k++) At[i * M + k] *= s;
+  }
+  return true;
+}
+
 // cv::SVD::compute(A (m x n)).  Scratch buffers ta (max(m,n)^2 when full_uv, else min*max) and tv (min^2)
 // are supplied by the caller.  U (m x ucols) and Vt (vrows x n) may be null.
 __device__ GL_NOINLINE void gl_svd_compute(const double* A, int m, int n, double* w, double* U, double* Vt, bool full_uv,
