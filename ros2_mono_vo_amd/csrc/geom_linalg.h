@@ -426,18 +426,66 @@ __device__ inline void gl_solve_svd(const double* A, int m, int n, const double*
 }
 
 // cv::invert(A 3x3, DECOMP_SVD)
-__device__ inline void gl_invert3_svd(const double* A, double* Ainv) {
+__device__ GL_NOINLINE void gl_invert3_svd_general(const double* A, double* Ainv) {
   double at[9], w[3], vt[9], buf[3];
   for (int i = 0; i < 3; i++)
     for (int j = 0; j < 3; j++) at[j * 3 + i] = A[i * 3 + j];
   gl_jacobi_svd(at, 3, w, vt, 3, 3, 3);
   gl_svbksb(3, 3, w, at, 3, vt, 3, nullptr, 0, 3, Ainv, 3, buf);
 }
+__device__ inline void gl_invert3_svd(const double* A, double* Ainv) {
+  double at[9], w[3], vt[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) at[j * 3 + i] = A[i * 3 + j];
+  if (!gl_jacobi_svd_fixed<3, 3>(at, w, vt)) { gl_invert3_svd_general(A, Ainv); return; }
+  // SVBkSb with b = identity (pseudo-inverse), same accumulation order as gl_svbksb's nb > 1 branch
+  const double eps = DBL_EPSILON * 2;
+  double threshold = (w[0] + w[1] + w[2]) * eps;
+#pragma unroll
+  for (int k = 0; k < 9; k++) Ainv[k] = 0;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    double wi = w[i];
+    if (fabs(wi) <= threshold) continue;
+    wi = 1 / wi;
+    double buf[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) buf[j] = at[i * 3 + j] * wi;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      double sv = vt[i * 3 + k];
+#pragma unroll
+      for (int j = 0; j < 3; j++) Ainv[k * 3 + j] = Ainv[k * 3 + j] + sv * buf[j];
+    }
+  }
+}
 
-// SVD of a 3x3 (U, w, Vt)
-__device__ inline void gl_svd3(const double* A, double* w, double* U, double* Vt) {
+// SVD of a 3x3 (U, w, Vt); U / Vt may be null
+__device__ GL_NOINLINE void gl_svd3_general(const double* A, double* w, double* U, double* Vt) {
   double ta[9], tv[9];
   gl_svd_compute(A, 3, 3, w, U, Vt, false, ta, tv);
+}
+__device__ inline void gl_svd3(const double* A, double* w, double* U, double* Vt) {
+  double ta[9], ww[3], tv[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) ta[j * 3 + i] = A[i * 3 + j];
+  if (!gl_jacobi_svd_fixed<3, 3>(ta, ww, tv)) { gl_svd3_general(A, w, U, Vt); return; }
+#pragma unroll
+  for (int i = 0; i < 3; i++) w[i] = ww[i];
+  if (U) {
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) U[k * 3 + i] = ta[i * 3 + k];
+  }
+  if (Vt) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) Vt[i] = tv[i];
+  }
 }
 
 // cv::solveCubic (4 double coefficients)
