@@ -566,7 +566,7 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
       for (int a = 0; a < 6; a++)
         for (int b = a; b < 6; b++) { Am[a * 6 + b] = JtJ[q]; Am[b * 6 + a] = JtJ[q]; q++; }
       for (int i = 0; i < 6; i++) Am[i * 6 + i] *= 1. + lambda;
-      gl_solve_svd_ws(Am, 6, 6, JtErr, x, s_mat + 40, s_mat + 80);
+      if (!gl_solve_svd_fixed<6, 6>(Am, JtErr, x)) gl_solve_svd_ws(Am, 6, 6, JtErr, x, s_mat + 40, s_mat + 80);
       for (int i = 0; i < 6; i++) s_sh[i] = prevParam[i] - x[i];
     }
     __syncthreads();

@@ -407,6 +407,39 @@ __device__ GL_NOINLINE void gl_svbksb(int m, int n, const double* w, const doubl
   }
 }
 
+// cv::solve(A (M x N), b, x, DECOMP_SVD) with the factorisation in registers (same sequence as gl_solve_svd: Jacobi SVD of
+// A^T, then SVBkSb's single right-hand-side branch).  Returns false for the rank-deficient completion case, which the
+// caller hands to gl_solve_svd_ws.
+template <int M, int N>
+__device__ __forceinline__ bool gl_solve_svd_fixed(const double* A, const double* b, double* x) {
+  double at[N * M], w[N], vt[N * N];
+#pragma unroll
+  for (int i = 0; i < M; i++)
+#pragma unroll
+    for (int j = 0; j < N; j++) at[j * M + i] = A[i * N + j];
+  if (!gl_jacobi_svd_fixed<M, N>(at, w, vt)) return false;
+  const double eps = DBL_EPSILON * 2;
+  double threshold = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) threshold += w[i];
+  threshold *= eps;
+#pragma unroll
+  for (int j = 0; j < N; j++) x[j] = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    double wi = w[i];
+    if (fabs(wi) <= threshold) continue;
+    wi = 1 / wi;
+    double sacc = 0;
+#pragma unroll
+    for (int j = 0; j < M; j++) sacc += at[i * M + j] * b[j];
+    sacc *= wi;
+#pragma unroll
+    for (int j = 0; j < N; j++) x[j] = x[j] + sacc * vt[i * N + j];
+  }
+  return true;
+}
+
 // cv::solve(A (m x n, m >= n <= 6), b, x, DECOMP_SVD) with caller-supplied workspaces (e.g. in LDS): at >= m*n, vt >= n*n
 __device__ inline void gl_solve_svd_ws(const double* A, int m, int n, const double* b, double* x, double* at, double* vt) {
   double w[6], buf[1];
