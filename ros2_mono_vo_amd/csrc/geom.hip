@@ -56,10 +56,14 @@ struct RansacArgs {
 
 template <class M>
 __global__ __launch_bounds__(RS_T, RS_WAVES_PER_EU) void ransac_kernel(RansacArgs A) {
-  constexpr int RS_CH = M::CH, RS_PARTS = RS_T / RS_CH;
+  // Round width.  The first round (and any round with few iterations left) solves CH0 = M::CH hypotheses, whose dense
+  // matrices live in LDS; when more than that many iterations are still owed, the round is 64 wide and lanes >= CH0 keep
+  // their matrices in private memory (slower per solve, four times the hypotheses per round) - the tail of a hard
+  // problem otherwise gates the whole batch launch.
+  constexpr int CH0 = M::CH, RS_CH = 64;
   // per-lane workspace stride: == 1 (mod 32) doubles, so lane-uniform 8-byte accesses of 16 lanes fall into distinct banks
   constexpr int WSS = M::WS > 0 ? ((M::WS + 30) / 32) * 32 + 1 : 1;
-  __shared__ double s_ws[(M::WS > 0 ? RS_CH : 1) * WSS];
+  __shared__ double s_ws[(M::WS > 0 ? CH0 : 1) * WSS];
   __shared__ int s_att[RS_CH][M::MP];
   __shared__ int s_idx[RS_CH][M::MP];
   __shared__ double s_models[RS_CH][M::MAXM][M::MS];
@@ -118,11 +122,12 @@ __global__ __launch_bounds__(RS_T, RS_WAVES_PER_EU) void ransac_kernel(RansacArg
 #define RS_TICK(k)
 #endif
   for (;;) {
+    const int ch = (M::WS > 0 && s_ctl[4] - s_ctl[3] <= CH0) || (M::WS > 0 && s_ctl[3] == 0) ? CH0 : RS_CH;  // uniform
     // ---- 1. candidate samples, OpenCV's getSubset draw order (sequential RNG stream, lane 0) ----------
     if (tid == 0) {
       GlRng rng(s_rng);
       // never draw (much) more than can still be consumed: iterations left, with head-room for checkSubset rejects
-      for (int a = 0; a < RS_CH; a++) {
+      for (int a = 0; a < ch; a++) {
         for (int i = 0; i < M::MP; ++i) {
           int idx_i;
           for (;;) {
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(RS_T, RS_WAVES_PER_EU) void ransac_kernel(RansacArg
     // ---- 2. checkSubset in parallel (one candidate per lane) + ordered compaction over the 4 waves -------
     float ms1[M::MP * M::PT1], ms2[M::MP * M::PT2];
     bool pass = false;
-    if (tid < RS_CH) {
+    if (tid < ch) {
       for (int i = 0; i < M::MP; i++) {
         int id = s_att[tid][i];
         for (int k = 0; k < M::PT1; k++) ms1[i * M::PT1 + k] = m1[(size_t)id * M::PT1 + k];
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(RS_T, RS_WAVES_PER_EU) void ransac_kernel(RansacArg
       // OpenCV gives up on an iteration after 10000 consecutive failing attempts: walk the pass bits in order
       int np = 0, run = s_ctl[5];
       bool abort_ = false;
-      constexpr int CPW = RS_CH < 64 ? RS_CH : 64;  // candidates held by one wave's ballot
+      const int CPW = ch;  // candidates held by the wave's ballot
       for (int w = 0; w < RS_NW; w++) {
         unsigned long long m = s_wmask[w];
         np += __popcll(m);
@@ -193,7 +198,8 @@ __global__ __launch_bounds__(RS_T, RS_WAVES_PER_EU) void ransac_kernel(RansacArg
         for (int k = 0; k < M::PT2; k++) ms2[i * M::PT2 + k] = m2[(size_t)id * M::PT2 + k];
       }
       double models[M::MAXM * M::MS];
-      nm = M::solve(A.P, ms1, ms2, models, s_ws + (M::WS > 0 ? tid * WSS : 0));
+      double priv[M::WS > 0 ? M::WS : 1];  // lanes >= CH0 of a wide round
+      nm = M::solve(A.P, ms1, ms2, models, M::WS > 0 ? (tid < CH0 ? s_ws + tid * WSS : priv) : s_ws);
       if (nm < 0) nm = 0;
       if (nm > M::MAXM) nm = M::MAXM;
       s_nmodels[tid] = nm;
@@ -204,15 +210,15 @@ __global__ __launch_bounds__(RS_T, RS_WAVES_PER_EU) void ransac_kernel(RansacArg
     RS_TICK(2)
     // ---- 4. scoring: hypothesis = tid % RS_CH, point partition = tid / RS_CH; integer inlier counts ------------
     {
-      const int hyp = tid % RS_CH, part = tid / RS_CH;
+      const int parts = RS_T / ch, hyp = tid % ch, part = tid / ch;
       if (hyp < nsolve) {
         const int nmh = s_nmodels[hyp];
         for (int q = 0; q < nmh; q++) {
           typename M::Scorer sc;
           sc.init(A.P, &s_models[hyp][q][0]);
           int good = 0;
-          for (int i = part; i < count; i += RS_PARTS) good += sc.err(m1 + (size_t)i * M::PT1, m2 + (size_t)i * M::PT2) <= t;
-          if (RS_PARTS == 1) s_cnt[hyp][q] = good; else atomicAdd(&s_cnt[hyp][q], good);
+          for (int i = part; i < count; i += parts) good += sc.err(m1 + (size_t)i * M::PT1, m2 + (size_t)i * M::PT2) <= t;
+          atomicAdd(&s_cnt[hyp][q], good);
         }
       }
     }
@@ -522,7 +528,7 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
       for (int a = 0; a < 12; a++)
         for (int b = a; b < 12; b++) { L[a * 12 + b] = LL[q]; L[b * 12 + a] = LL[q]; q++; }
       // cvSVD(&_LL, &_LW, 0, &_LV, MODIFY_A + V_T): Vt; run the one-sided Jacobi on L^T (= L)
-      gl_jacobi_svd(L, 12, LW, LV, 12, 12, 12);
+      gl_jacobi_svd12_lds((gl_lds_double*)L, (gl_lds_double*)LW, (gl_lds_double*)LV);
       double* RRt = LV + 11 * 12;
       double RR[9], ttv[3];
       for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) RR[r * 3 + c] = RRt[r * 4 + c]; ttv[r] = RRt[r * 4 + 3]; }

@@ -125,62 +125,12 @@ __device__ GL_NOINLINE void gl_jacobi_eigen(double* A, int n, double* W, double*
   }
 }
 
-// JacobiSVDImpl_<double>: At has n rows of length m (stride astep); rows 0..n1-1 become left singular
-// vectors (the rows beyond n are the seeded Gram-Schmidt completion); Vt n x n.
-__device__ GL_NOINLINE void gl_jacobi_svd(double* At, int astep, double* Wout, double* Vt, int m, int n, int n1) {
+// Second half of JacobiSVDImpl_: singular values, descending sort (rows of At / Vt follow), unit left vectors, and the
+// seeded Gram-Schmidt completion for vanishing singular values.  W: squared row norms are NOT needed, it is recomputed.
+__device__ GL_NOINLINE void gl_jacobi_svd_tail(double* At, int astep, double* W, double* Wout, double* Vt, int m, int n, int n1) {
   const double minval = DBL_MIN, eps = DBL_EPSILON * 10;
-  double W[GL_MAXN];
-  int i, j, k, iter, max_iter = m > 30 ? m : 30;
-  double c, s, sd;
-  for (i = 0; i < n; i++) {
-    for (k = 0, sd = 0; k < m; k++) {
-      double t = At[i * astep + k];
-      sd += t * t;
-    }
-    W[i] = sd;
-    if (Vt) {
-      for (k = 0; k < n; k++) Vt[i * n + k] = 0;
-      Vt[i * n + i] = 1;
-    }
-  }
-  for (iter = 0; iter < max_iter; iter++) {
-    bool changed = false;
-    for (i = 0; i < n - 1; i++)
-      for (j = i + 1; j < n; j++) {
-        double *Ai = At + i * astep, *Aj = At + j * astep;
-        double a = W[i], p = 0, b = W[j];
-        for (k = 0; k < m; k++) p += Ai[k] * Aj[k];
-        if (fabs(p) <= eps * sqrt(a * b)) continue;
-        p *= 2;
-        double beta = a - b, gamma = gl_hypot(p, beta);
-        if (beta < 0) {
-          double delta = (gamma - beta) * 0.5;
-          s = sqrt(delta / gamma);
-          c = p / (gamma * s * 2);
-        } else {
-          c = sqrt((gamma + beta) / (gamma * 2));
-          s = p / (gamma * c * 2);
-        }
-        a = b = 0;
-        for (k = 0; k < m; k++) {
-          double t0 = c * Ai[k] + s * Aj[k];
-          double t1 = -s * Ai[k] + c * Aj[k];
-          Ai[k] = t0; Aj[k] = t1;
-          a += t0 * t0; b += t1 * t1;
-        }
-        W[i] = a; W[j] = b;
-        changed = true;
-        if (Vt) {
-          double *Vi = Vt + i * n, *Vj = Vt + j * n;
-          for (k = 0; k < n; k++) {
-            double t0 = c * Vi[k] + s * Vj[k];
-            double t1 = -s * Vi[k] + c * Vj[k];
-            Vi[k] = t0; Vj[k] = t1;
-          }
-        }
-      }
-    if (!changed) break;
-  }
+  int i, j, k, iter;
+  double s, sd;
   for (i = 0; i < n; i++) {
     for (k = 0, sd = 0; k < m; k++) {
       double t = At[i * astep + k];
@@ -235,6 +185,146 @@ __device__ GL_NOINLINE void gl_jacobi_svd(double* At, int astep, double* Wout, d
     s = sd > minval ? 1 / sd : 0.;
     for (k = 0; k < m; k++) At[i * astep + k] *= s;
   }
+}
+
+// JacobiSVDImpl_<double>: At has n rows of length m (stride astep); rows 0..n1-1 become left singular
+// vectors (the rows beyond n are the seeded Gram-Schmidt completion); Vt n x n.
+__device__ GL_NOINLINE void gl_jacobi_svd(double* At, int astep, double* Wout, double* Vt, int m, int n, int n1) {
+  const double eps = DBL_EPSILON * 10;
+  double W[GL_MAXN];
+  int i, j, k, iter, max_iter = m > 30 ? m : 30;
+  double c, s, sd;
+  for (i = 0; i < n; i++) {
+    for (k = 0, sd = 0; k < m; k++) {
+      double t = At[i * astep + k];
+      sd += t * t;
+    }
+    W[i] = sd;
+    if (Vt) {
+      for (k = 0; k < n; k++) Vt[i * n + k] = 0;
+      Vt[i * n + i] = 1;
+    }
+  }
+  for (iter = 0; iter < max_iter; iter++) {
+    bool changed = false;
+    for (i = 0; i < n - 1; i++)
+      for (j = i + 1; j < n; j++) {
+        double *Ai = At + i * astep, *Aj = At + j * astep;
+        double a = W[i], p = 0, b = W[j];
+        for (k = 0; k < m; k++) p += Ai[k] * Aj[k];
+        if (fabs(p) <= eps * sqrt(a * b)) continue;
+        p *= 2;
+        double beta = a - b, gamma = gl_hypot(p, beta);
+        if (beta < 0) {
+          double delta = (gamma - beta) * 0.5;
+          s = sqrt(delta / gamma);
+          c = p / (gamma * s * 2);
+        } else {
+          c = sqrt((gamma + beta) / (gamma * 2));
+          s = p / (gamma * c * 2);
+        }
+        a = b = 0;
+        for (k = 0; k < m; k++) {
+          double t0 = c * Ai[k] + s * Aj[k];
+          double t1 = -s * Ai[k] + c * Aj[k];
+          Ai[k] = t0; Aj[k] = t1;
+          a += t0 * t0; b += t1 * t1;
+        }
+        W[i] = a; W[j] = b;
+        changed = true;
+        if (Vt) {
+          double *Vi = Vt + i * n, *Vj = Vt + j * n;
+          for (k = 0; k < n; k++) {
+            double t0 = c * Vi[k] + s * Vj[k];
+            double t1 = -s * Vi[k] + c * Vj[k];
+            Vi[k] = t0; Vj[k] = t1;
+          }
+        }
+      }
+    if (!changed) break;
+  }
+  gl_jacobi_svd_tail(At, astep, W, Wout, Vt, m, n, n1);
+}
+
+// The 12 x 12 case of JacobiSVDImpl_ (EPnP's M^T M, the DLT of cvFindExtrinsicCameraParams2) with the matrices in LDS:
+// same operation sequence as gl_jacobi_svd, but the inner k loops are unrolled (12 independent ds_read_b64 in flight
+// instead of one flat load per element) and row i of At / Vt stays in registers while j runs.  P is a pointer into
+// address space 3.  W (12 doubles, LDS) doubles as the singular-value output.
+typedef __attribute__((address_space(3))) double gl_lds_double;
+// true when a generic pointer lies in the LDS aperture (device pass only; the host pass never runs this code)
+__device__ __forceinline__ bool gl_is_lds(const void* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_is_shared(p);
+#else
+  (void)p;
+  return false;
+#endif
+}
+__device__ inline void gl_jacobi_svd12_lds(gl_lds_double* At, gl_lds_double* W, gl_lds_double* Vt) {
+  const double eps = DBL_EPSILON * 10;
+  for (int i = 0; i < 12; i++) {
+    double sd = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) { double t = At[i * 12 + k]; sd += t * t; }
+    W[i] = sd;
+#pragma unroll
+    for (int k = 0; k < 12; k++) Vt[i * 12 + k] = 0;
+    Vt[i * 12 + i] = 1;
+  }
+  for (int iter = 0; iter < 30; iter++) {
+    bool changed = false;
+    for (int i = 0; i < 11; i++) {
+      double Ai[12], Vi[12];
+#pragma unroll
+      for (int k = 0; k < 12; k++) { Ai[k] = At[i * 12 + k]; Vi[k] = Vt[i * 12 + k]; }
+      double a = W[i];
+      bool touched = false;
+      for (int j = i + 1; j < 12; j++) {
+        double Aj[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) Aj[k] = At[j * 12 + k];
+        double p = 0, b = W[j];
+#pragma unroll
+        for (int k = 0; k < 12; k++) p += Ai[k] * Aj[k];
+        if (fabs(p) <= eps * sqrt(a * b)) continue;
+        p *= 2;
+        double beta = a - b, gamma = gl_hypot(p, beta), c, s;
+        if (beta < 0) {
+          double delta = (gamma - beta) * 0.5;
+          s = sqrt(delta / gamma);
+          c = p / (gamma * s * 2);
+        } else {
+          c = sqrt((gamma + beta) / (gamma * 2));
+          s = p / (gamma * c * 2);
+        }
+        a = b = 0;
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+          double t0 = c * Ai[k] + s * Aj[k];
+          double t1 = -s * Ai[k] + c * Aj[k];
+          Ai[k] = t0; At[j * 12 + k] = t1;
+          a += t0 * t0; b += t1 * t1;
+        }
+        W[j] = b;
+        touched = true;
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+          double vj = Vt[j * 12 + k];
+          double t0 = c * Vi[k] + s * vj;
+          double t1 = -s * Vi[k] + c * vj;
+          Vi[k] = t0; Vt[j * 12 + k] = t1;
+        }
+      }
+      if (touched) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) { At[i * 12 + k] = Ai[k]; Vt[i * 12 + k] = Vi[k]; }
+        W[i] = a;
+        changed = true;
+      }
+    }
+    if (!changed) break;
+  }
+  gl_jacobi_svd_tail((double*)At, 12, (double*)W, (double*)W, (double*)Vt, 12, 12, 12);
 }
 
 // JacobiSVDImpl_<double> for compile-time sizes, everything in registers: the same operation sequence as

@@ -450,7 +450,7 @@ __device__ GL_NOINLINE double ep_compute_R_and_t(EpnpState& e, const double* ut,
 }
 
 // solvePnP(SOLVEPNP_EPNP) for 5 float correspondences -> rvec, tvec
-// ws: 288 doubles (LDS).  [0,144) MtM, rotated in place into Ut by the SVD; [144,288) first M (2n x 12), then the SVD's V,
+// ws: 300 doubles.  [288,300) singular values; [0,144) MtM, rotated in place into Ut by the SVD; [144,288) first M (2n x 12), then the SVD's V,
 // then the workspaces of the three small least-squares solves.
 __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const CamK& cam, double rvec[3], double tvec[3], double* ws) {
   const int n = EP_N;
@@ -527,7 +527,10 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
     // Ut rows = left singular vectors = rows of the rotated A^T: run the one-sided Jacobi directly on mtm^T
     for (int i = 0; i < 12; i++)
       for (int j = i + 1; j < 12; j++) { double t = mtm[i * 12 + j]; mtm[i * 12 + j] = mtm[j * 12 + i]; mtm[j * 12 + i] = t; }
-    gl_jacobi_svd(mtm, 12, d, tv, 12, 12, 12);  // ut == mtm
+    // ut == mtm.  Lanes whose workspace is in LDS take the unrolled 12 x 12 routine; the private-memory lanes of a wide
+    // RANSAC round take the general one (same arithmetic)
+    if (gl_is_lds(ws)) gl_jacobi_svd12_lds((gl_lds_double*)mtm, (gl_lds_double*)(ws + 288), (gl_lds_double*)tv);
+    else gl_jacobi_svd(mtm, 12, d, tv, 12, 12, 12);
   }
   double l_6x10[60], rho[6];
   {
@@ -610,7 +613,7 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
 
 struct PnPModel {
   static constexpr int MP = 5, MAXM = 1, MS = 6, PT1 = 3, PT2 = 2;
-  static constexpr int CH = 16, WS = 144 + 144;  // MtM -> Ut, and M / V / the small solves' workspaces
+  static constexpr int CH = 16, WS = 144 + 144 + 12;  // MtM -> Ut; M / V / the small solves' workspaces; singular values
   __device__ static bool check_subset(const float*, const float*) { return true; }
   __device__ static int solve(const ModelParams& P, const float* ms1, const float* ms2, double* model, double* ws) {
     double rvec[3], tvec[3];
