@@ -108,6 +108,21 @@ inline std::vector<cv::Point3f> triangulate(mvo_ctx* ctx, const cv::Mat& P1, con
   return X;
 }
 
+// Replaces cv::findEssentialMat(p1, p2, K, cv::RANSAC, prob, thr, mask) at reference src/initializer.cpp:228-229.
+// Returns the 3x3 essential matrix (empty when no model was found, like OpenCV); mask gets one byte per point.
+inline cv::Mat find_essential_mat(mvo_ctx* ctx, const std::vector<cv::Point2f>& p1, const std::vector<cv::Point2f>& p2, const cv::Mat& K,
+                                  double prob, double thr, std::vector<uchar>& mask) {
+  cv::Mat Kd;
+  K.convertTo(Kd, CV_64F); Kd = Kd.clone();
+  mask.assign(p1.size(), 0);
+  cv::Mat E(3, 3, CV_64F);
+  int n_inl = 0;
+  int rc = mvo_find_essential_ransac(ctx, reinterpret_cast<const float*>(p1.data()), reinterpret_cast<const float*>(p2.data()), (int)p1.size(),
+                                     Kd.ptr<double>(), prob, thr, 1000, mask.data(), E.ptr<double>(), &n_inl);
+  check(ctx, rc, true);
+  return rc == MVO_OK ? E : cv::Mat();
+}
+
 // Replaces cv::recoverPose(E, p1, p2, K, R, t, mask) at reference src/initializer.cpp:236.
 inline int recover_pose(mvo_ctx* ctx, const cv::Mat& E, const std::vector<cv::Point2f>& p1, const std::vector<cv::Point2f>& p2, const cv::Mat& K,
                         cv::Mat& R, cv::Mat& t, std::vector<uchar>& mask) {
