@@ -151,9 +151,11 @@ def main():
         # HBM traffic of the kernel from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes;
         # profiles/r01_lk_pmc.json holds the measured bytes per tracked point), scaled to this launch's point count.
         traffic = None
+        valu = {}
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_lk_pmc.json")))
             traffic = int((pmc["fetch_bytes_per_point"] + pmc["write_bytes_per_point"]) * (lk_points / max(K, 1)))
+            valu = pmc.get("sq_pass", {})
         except Exception:
             pass
         line = {
@@ -177,7 +179,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "lk_track_kernel", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": lk["ms_avg"]},
+                         "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": lk["ms_avg"],
+                         # the kernel is VALU bound, not memory bound (PMC SQ pass, profiles/r01_lk_pmc.json)
+                         "valu_instructions_per_point": valu.get("valu_instructions_per_point"),
+                         "valu_busy_frac_of_simd_time": valu.get("valu_busy_fraction_of_simd_time_at_2.4GHz")},
             "stage_ms": prof,
         }
         if not args.no_cpu_baseline:

@@ -2,24 +2,24 @@
 // src/feature_processor.cpp:19-23; semantics per SURVEY.md Appendix A.1 and oracle/orc_orb.cpp).
 //
 // Device pipeline, every launch covering all slots of the batch:
-//   resize_exact_kernel   8-level pyramid, INTER_LINEAR_EXACT 8.8 x 8.8 fixed point (level l from l-1)
-//   fast_nms_kernel       FAST-9/16 + cornerScore + strict 3x3 NMS fused per 64x16 tile: antipodal-pair reject,
-//                         ballot-compacted candidate list in LDS, full score for candidates only, dword stores
-//   nms_rows_kernel<0/1>  edgeThreshold cull + ORDERED (row-major) compaction of the non-zero map entries; one
-//                         wavefront per image row, 4 pixels per lane, __ballot + popcount: pass 0 counts, pass 1 emits
+//   resize_exact_kernel   8-level pyramid, INTER_LINEAR_EXACT 8.8 x 8.8 fixed point (level l from l-1), table driven
+//   fast_nms_kernel       FAST-9/16 + cornerScore + strict 3x3 NMS fused per 64x32 tile: packed 4-point pre-test,
+//                         ballot-compacted candidate list in LDS, full score for candidates only, dword stores,
+//                         per-row survivor counts (atomics) for the compaction
 //   scan_rows/scan_slots  exclusive scans (rows -> levels -> slots) so candidates of the whole batch are
 //                         one dense array
-//   [host]                KeyPointsFilter::retainBest twice per level with libstdc++ nth_element/partition
-//                         on the response arrays only: that permutation IS OpenCV's key-point order
-//   ic_angle_kernel       intensity-centroid orientation, one wavefront per key-point, exact int moments
+//   nms_rows_kernel<1>    edgeThreshold cull + ORDERED (row-major) emit of the non-zero map entries; one wavefront
+//                         per image row, 4 pixels per lane, __ballot + popcount
+//   orb_select_kernel     (orb_select.hip) KeyPointsFilter::retainBest twice per level in libstdc++'s
+//                         nth_element/partition element order - that permutation IS OpenCV's key-point order -
+//                         with the Harris responses of the first pass's survivors computed in between
 //   blur7_kernel          7x7 Gaussian in the 8-bit fixed point ORB gets: v_dot4_u32_u8 rows, v_dot2_u32_u16 columns
+//   ic_angle_kernel       intensity-centroid orientation, half a wavefront per key-point, exact int moments
 //   brief_kernel          rotated BRIEF, 32 lanes per key-point (one descriptor byte per lane)
 #include "mvo_internal.h"
 
 #include <algorithm>
-#include <atomic>
 #include <cmath>
-#include <thread>
 
 static const int kOrbPattern31[256 * 4] = {
 #include "orb_pattern_31.inc"
