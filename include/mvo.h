@@ -138,7 +138,10 @@ int mvo_find_fundamental_ransac(mvo_ctx* ctx, const float* p1, const float* p2, 
                                 int* n_inliers);
 
 /* ---- a4: Tracker::update PnP section (src/tracker.cpp:300-316) -----------------------------------
- * cv::solvePnPRansac(obj, img, K, d, rvec, tvec, false, iters, reproj, conf, inliers). */
+ * cv::solvePnPRansac(obj, img, K, d, rvec, tvec, false, iters, reproj, conf, inliers).
+ * d: NULL / zeros, or the 5 plumb-bob coefficients (k1, k2, p1, p2, k3) of sensor_msgs/CameraInfo::d as the reference
+ * forwards them: undistortPoints (5 iterations) in the EPnP kernel and the DLT / planar init, distorted projectPoints in
+ * the RANSAC error and the Levenberg-Marquardt refine.  n == 4 (P3P) is not built: MVO_E_ARG. */
 int mvo_solve_pnp_ransac(mvo_ctx* ctx, const float* obj, const float* img, int n, const double K[9],
                          const double d[5], int iters, float reproj_err, double confidence, double rvec[3],
                          double tvec[3], int* inlier_idx, int* n_inliers);

@@ -84,28 +84,74 @@ static void rodrigues_m2v(const double Rin[9], double r[3]) {
   r[0] = rx; r[1] = ry; r[2] = rz;
 }
 
-// ---- cvProjectPoints2 with zero distortion: m = K [R|t] M, optional d m/d r (2x3) and d m/d t (2x3) ---
-struct Cam { double fx, fy, cx, cy; };
+// ---- cvProjectPoints2: m = K * distort([R|t] M), optional d m/d r (2x3) and d m/d t (2x3) -------------
+// Distortion model: the 5-coefficient plumb-bob set the reference forwards from sensor_msgs/CameraInfo::d
+// (k1, k2, p1, p2, k3); OpenCV's rational / thin-prism / tilt terms (k4..k6, s1..s4, tau) are zero.
+struct Cam {
+  double fx, fy, cx, cy;
+  double k[5] = {0, 0, 0, 0, 0};
+  bool dist = false;
+};
+
+static Cam make_cam(const double* K, const double* d) {
+  Cam c;
+  c.fx = K[0]; c.fy = K[4]; c.cx = K[2]; c.cy = K[5];
+  for (int i = 0; i < 5; i++) { c.k[i] = d ? d[i] : 0.0; c.dist = c.dist || c.k[i] != 0.0; }
+  return c;
+}
+
+// cvUndistortPointsInternal for one pixel, identity R, no P: 5 fixed-point iterations (TermCriteria COUNT 5)
+static void undistort_point(const Cam& cam, double u, double v, double& xo, double& yo) {
+  const double ifx = 1. / cam.fx, ify = 1. / cam.fy;
+  double x = (u - cam.cx) * ifx, y = (v - cam.cy) * ify;
+  if (cam.dist) {
+    const double* k = cam.k;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+      double r2 = x * x + y * y;
+      double icdist = 1. / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+      if (icdist < 0) { x = (u - cam.cx) * ifx; y = (v - cam.cy) * ify; break; }
+      double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x);
+      double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y;
+      x = (x0 - deltaX) * icdist;
+      y = (y0 - deltaY) * icdist;
+    }
+  }
+  xo = x; yo = y;
+}
 
 static void project_point(const double R[9], const double dRdr[27], const double t[3], const Cam& cam, const double M[3],
                           double m[2], double* dpdr /* 6 */, double* dpdt /* 6 */) {
+  const double* k = cam.k;
   double X = M[0], Y = M[1], Z = M[2];
   double x = R[0] * X + R[1] * Y + R[2] * Z + t[0];
   double y = R[3] * X + R[4] * Y + R[5] * Z + t[1];
   double z = R[6] * X + R[7] * Y + R[8] * Z + t[2];
   z = z ? 1. / z : 1;
   x *= z; y *= z;
-  // zero distortion: cdist = icdist2 = 1, tangential / thin-prism / tilt terms vanish
-  double xd = x, yd = y;
+  double r2 = 0, r4 = 0, cdist = 1, xd = x, yd = y;
+  if (cam.dist) {
+    r2 = x * x + y * y; r4 = r2 * r2;
+    double r6 = r4 * r2, a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
+    cdist = 1 + k[0] * r2 + k[1] * r4 + k[4] * r6;
+    xd = x * cdist + k[2] * a1 + k[3] * a2;
+    yd = y * cdist + k[2] * a3 + k[3] * a1;
+  }
   m[0] = xd * cam.fx + cam.cx;
   m[1] = yd * cam.fy + cam.cy;
   if (dpdt) {
     double dxdt[] = {z, 0, -x * z}, dydt[] = {0, z, -y * z};
     for (int j = 0; j < 3; j++) {
-      double dmxdt = cam.fx * dxdt[j];   // cdist*icdist2 = 1, no radial/tangential contribution at d = 0
-      double dmydt = cam.fy * dydt[j];
-      dpdt[j] = dmxdt;
-      dpdt[3 + j] = dmydt;
+      double dmxdt = dxdt[j], dmydt = dydt[j];
+      if (cam.dist) {
+        double dr2dt = 2 * x * dxdt[j] + 2 * y * dydt[j];
+        double dcdist_dt = k[0] * dr2dt + 2 * k[1] * r2 * dr2dt + 3 * k[4] * r4 * dr2dt;
+        double da1dt = 2 * (x * dydt[j] + y * dxdt[j]);
+        dmxdt = dxdt[j] * cdist + x * dcdist_dt + k[2] * da1dt + k[3] * (dr2dt + 4 * x * dxdt[j]);
+        dmydt = dydt[j] * cdist + y * dcdist_dt + k[2] * (dr2dt + 4 * y * dydt[j]) + k[3] * da1dt;
+      }
+      dpdt[j] = cam.fx * dmxdt;
+      dpdt[3 + j] = cam.fy * dmydt;
     }
   }
   if (dpdr) {
@@ -118,8 +164,16 @@ static void project_point(const double R[9], const double dRdr[27], const double
     for (int j = 0; j < 3; j++) {
       double dxdr = z * (dx0dr[j] - x * dz0dr[j]);
       double dydr = z * (dy0dr[j] - y * dz0dr[j]);
-      dpdr[j] = cam.fx * dxdr;
-      dpdr[3 + j] = cam.fy * dydr;
+      double dmxdr = dxdr, dmydr = dydr;
+      if (cam.dist) {
+        double dr2dr = 2 * x * dxdr + 2 * y * dydr;
+        double dcdist_dr = (k[0] + 2 * k[1] * r2 + 3 * k[4] * r4) * dr2dr;
+        double da1dr = 2 * (x * dydr + y * dxdr);
+        dmxdr = dxdr * cdist + x * dcdist_dr + k[2] * da1dr + k[3] * (dr2dr + 4 * x * dxdr);
+        dmydr = dydr * cdist + y * dcdist_dr + k[2] * (dr2dr + 4 * y * dydr) + k[3] * da1dr;
+      }
+      dpdr[j] = cam.fx * dmxdr;
+      dpdr[3 + j] = cam.fy * dmydr;
     }
   }
 }
@@ -437,12 +491,12 @@ static void solve_pnp_epnp(const float* obj, const float* img, int count, const 
   e.fu = cam.fx; e.fv = cam.fy; e.uc = cam.cx; e.vc = cam.cy;
   e.n = count;
   e.pws.resize(3 * count); e.us.resize(2 * count); e.alphas.resize(4 * count); e.pcs.resize(3 * count);
-  double ifx = 1. / cam.fx, ify = 1. / cam.fy;
   for (int i = 0; i < count; i++) {
     e.pws[3 * i] = obj[3 * i]; e.pws[3 * i + 1] = obj[3 * i + 1]; e.pws[3 * i + 2] = obj[3 * i + 2];
-    // cvUndistortPoints (d = 0) writes CV_32FC2; epnp::init_points re-applies fu, uc in double
-    float xn = (float)(((double)img[2 * i] - cam.cx) * ifx);
-    float yn = (float)(((double)img[2 * i + 1] - cam.cy) * ify);
+    // cvUndistortPoints writes CV_32FC2; epnp::init_points re-applies fu, uc in double
+    double xu, yu;
+    undistort_point(cam, (double)img[2 * i], (double)img[2 * i + 1], xu, yu);
+    float xn = (float)xu, yn = (float)yu;
     e.us[2 * i] = xn * e.fu + e.uc;
     e.us[2 * i + 1] = yn * e.fv + e.vc;
   }
@@ -576,7 +630,7 @@ extern "C" int orc_rodrigues_v2m(const double* r, double* R) { rodrigues_v2m(r, 
 extern "C" int orc_rodrigues_m2v(const double* R, double* r) { rodrigues_m2v(R, r); return 0; }
 
 extern "C" int orc_epnp(const float* obj, const float* img, int n, const double* K, double* rvec, double* tvec) {
-  Cam cam{K[0], K[4], K[2], K[5]};
+  Cam cam = make_cam(K, nullptr);
   solve_pnp_epnp(obj, img, n, cam, rvec, tvec);
   return 0;
 }
@@ -584,11 +638,9 @@ extern "C" int orc_epnp(const float* obj, const float* img, int n, const double*
 extern "C" int orc_solve_pnp_ransac(const float* obj, const float* img, int n, const double* K, const double* d, int iters,
                                     float reproj_err, double confidence, double* rvec, double* tvec, int* inlier_idx,
                                     int* n_inliers, int* stats) {
-  for (int i = 0; i < 5; i++)
-    if (d && d[i] != 0.0) return -3;  // distortion not restated
   if (n < 4) return -1;
   *n_inliers = 0;
-  Cam cam{K[0], K[4], K[2], K[5]};
+  Cam cam = make_cam(K, d);
   if (n == 4) return -2;  // P3P branch not restated (the tracker declares LOST below 10 points)
   PnPCb cb;
   cb.cam = cam;

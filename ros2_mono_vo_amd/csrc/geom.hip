@@ -364,7 +364,6 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
   const float* img = A.img + (size_t)slot * A.stride_pts * 2;
   const int* inl = A.inl + (size_t)slot * A.stride_pts;
   const CamK cam = A.cam;
-  const double ifx = 1. / cam.fx, ify = 1. / cam.fy;
   auto ptM = [&](int i, double M[3]) { int id = inl[i]; M[0] = obj[3 * id]; M[1] = obj[3 * id + 1]; M[2] = obj[3 * id + 2]; };
   auto ptm = [&](int i, double m[2]) { int id = inl[i]; m[0] = img[2 * id]; m[1] = img[2 * id + 1]; };
 
@@ -414,7 +413,7 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
       X = Rt[0] * M[0] + Rt[1] * M[1] + Rt[2] * M[2] + tt[0];
       Y = Rt[3] * M[0] + Rt[4] * M[1] + Rt[5] * M[2] + tt[1];
     };
-    auto mnorm = [&](int i, double& x, double& y) { double m[2]; ptm(i, m); x = (m[0] - cam.cx) * ifx; y = (m[1] - cam.cy) * ify; };
+    auto mnorm = [&](int i, double& x, double& y) { double m[2]; ptm(i, m); gm_undistort_point(cam, m[0], m[1], x, y); };
     // normalised DLT homography Mxy -> mn (HomographyEstimatorCallback::runKernel on all points)
     double c4[4];
     {
@@ -512,7 +511,9 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
     for (int k = 0; k < 78; k++) acc[k] = 0;
     for (int i = tid; i < count; i += PR_T) {
       double M[3], m[2]; ptM(i, M); ptm(i, m);
-      double x = -((m[0] - cam.cx) * ifx), y = -((m[1] - cam.cy) * ify);
+      double xu, yu;
+      gm_undistort_point(cam, m[0], m[1], xu, yu);
+      double x = -xu, y = -yu;
       double l0[12] = {M[0], M[1], M[2], 1., 0, 0, 0, 0, x * M[0], x * M[1], x * M[2], x};
       double l1[12] = {0, 0, 0, 0, M[0], M[1], M[2], 1., y * M[0], y * M[1], y * M[2], y};
       int q = 0;
@@ -806,11 +807,11 @@ int geom_ransac_f(mvo_ctx* ctx, int nslots, const float* p1, const float* p2, co
   launch_ransac<FModel>(ctx, st, nslots, p1, p2, ctx->maxpts * 2, ctx->maxpts * 2, d_n, thr, conf, max_iters, P, mask, ctx->maxpts, model, result);
   return MVO_OK;
 }
-int geom_pnp(mvo_ctx* ctx, int nslots, const float* obj, const float* img, const int* d_n, const double K[9], int iters, float reproj,
-             double conf, u8* mask, double* model, int* result, int* inl, double* pose, hipStream_t st) {
+int geom_pnp(mvo_ctx* ctx, int nslots, const float* obj, const float* img, const int* d_n, const double K[9], const double* dist5, int iters,
+             float reproj, double conf, u8* mask, double* model, int* result, int* inl, double* pose, hipStream_t st) {
   if (!st) st = ctx->stream;
   ModelParams P{};
-  P.cam = CamK{K[0], K[4], K[2], K[5]};
+  P.cam = make_camk(K, dist5);
   launch_ransac<PnPModel>(ctx, st, nslots, obj, img, ctx->maxpts * 3, ctx->maxpts * 2, d_n, (double)reproj, conf, iters, P, mask, ctx->maxpts,
                           model, result);
   hipLaunchKernelGGL(mask_to_indices_kernel, dim3(nslots), dim3(1024), 0, st, mask, ctx->maxpts, d_n, inl, ctx->maxpts, result);
@@ -948,14 +949,11 @@ extern "C" int mvo_solve_pnp_ransac(mvo_ctx* ctx, const float* obj, const float*
                                     int* n_inliers) {
   if (!ctx || !obj || !img || !K || !rvec || !tvec || n < 0) return MVO_E_ARG;
   if (n_inliers) *n_inliers = 0;
-  if (d)
-    for (int i = 0; i < 5; i++)
-      if (d[i] != 0.0) { ctx->set_error("non-zero distortion is not built (rectified input expected)"); return MVO_E_ARG; }
   if (n < 5) { ctx->set_error("solvePnPRansac: fewer than 5 points (P3P branch not built)"); return MVO_E_ARG; }
   GeomState* g = ctx->geom;
   int rc = upload_pairs(ctx, obj, 3, img, 2, n);
   if (rc) return rc;
-  geom_pnp(ctx, 1, g->d_m1, g->d_m2, g->d_n, K, iters, reproj_err, confidence, g->d_mask, g->d_model, g->d_result, g->d_inl, g->d_pose, nullptr);
+  geom_pnp(ctx, 1, g->d_m1, g->d_m2, g->d_n, K, d, iters, reproj_err, confidence, g->d_mask, g->d_model, g->d_result, g->d_inl, g->d_pose, nullptr);
   MVO_HIP(hipMemcpyAsync(g->h_model, g->d_pose, 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MVO_HIP(hipMemcpyAsync(g->h_result, g->d_result, 8 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   MVO_HIP(hipStreamSynchronize(ctx->stream));

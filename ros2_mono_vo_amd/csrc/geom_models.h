@@ -14,7 +14,14 @@
 #pragma once
 #include "geom_linalg.h"
 
-struct CamK { double fx, fy, cx, cy; };
+// Intrinsics + the 5-coefficient plumb-bob distortion (k1, k2, p1, p2, k3) the reference forwards from CameraInfo::d
+// (src/tracker.cpp:309).  `dist` = any coefficient non-zero; brace-initialising the first four members leaves it off.
+struct CamK { double fx, fy, cx, cy; double k[5]; int dist; };
+inline CamK make_camk(const double K[9], const double* d) {
+  CamK c{K[0], K[4], K[2], K[5], {0, 0, 0, 0, 0}, 0};
+  for (int i = 0; i < 5; i++) { c.k[i] = d ? d[i] : 0.0; c.dist = c.dist || c.k[i] != 0.0; }
+  return c;
+}
 struct ModelParams { CamK cam; };
 
 // ---------------------------------------------------------------------------------------------------
@@ -274,21 +281,59 @@ __device__ GL_NOINLINE void gm_rodrigues_m2v(const double Rin[9], double r[3]) {
   r[0] = rx; r[1] = ry; r[2] = rz;
 }
 
+// cvUndistortPointsInternal for one pixel (identity R, no P): 5 fixed-point iterations (TermCriteria COUNT 5)
+__device__ inline void gm_undistort_point(const CamK& cam, double u, double v, double& xo, double& yo) {
+  const double ifx = 1. / cam.fx, ify = 1. / cam.fy;
+  double x = (u - cam.cx) * ifx, y = (v - cam.cy) * ify;
+  if (cam.dist) {
+    const double* k = cam.k;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+      double r2 = x * x + y * y;
+      double icdist = 1. / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+      if (icdist < 0) { x = (u - cam.cx) * ifx; y = (v - cam.cy) * ify; break; }
+      double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x);
+      double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y;
+      x = (x0 - deltaX) * icdist;
+      y = (y0 - deltaY) * icdist;
+    }
+  }
+  xo = x; yo = y;
+}
+
+// cvProjectPoints2 for one point, optional d m / d r (2x3) and d m / d t (2x3)
 __device__ inline void gm_project_point(const double R[9], const double* dRdr, const double t[3], const CamK& cam,
                                         const double M[3], double m[2], double* dpdr, double* dpdt) {
+  const double* k = cam.k;
   double X = M[0], Y = M[1], Z = M[2];
   double x = R[0] * X + R[1] * Y + R[2] * Z + t[0];
   double y = R[3] * X + R[4] * Y + R[5] * Z + t[1];
   double z = R[6] * X + R[7] * Y + R[8] * Z + t[2];
   z = z ? 1. / z : 1;
   x *= z; y *= z;
-  m[0] = x * cam.fx + cam.cx;
-  m[1] = y * cam.fy + cam.cy;
+  double r2 = 0, r4 = 0, cdist = 1, xd = x, yd = y;
+  if (cam.dist) {
+    r2 = x * x + y * y; r4 = r2 * r2;
+    double r6 = r4 * r2, a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
+    cdist = 1 + k[0] * r2 + k[1] * r4 + k[4] * r6;
+    xd = x * cdist + k[2] * a1 + k[3] * a2;
+    yd = y * cdist + k[2] * a3 + k[3] * a1;
+  }
+  m[0] = xd * cam.fx + cam.cx;
+  m[1] = yd * cam.fy + cam.cy;
   if (dpdt) {
     double dxdt[3] = {z, 0, -x * z}, dydt[3] = {0, z, -y * z};
     for (int j = 0; j < 3; j++) {
-      dpdt[j] = cam.fx * dxdt[j];
-      dpdt[3 + j] = cam.fy * dydt[j];
+      double dmxdt = dxdt[j], dmydt = dydt[j];
+      if (cam.dist) {
+        double dr2dt = 2 * x * dxdt[j] + 2 * y * dydt[j];
+        double dcdist_dt = k[0] * dr2dt + 2 * k[1] * r2 * dr2dt + 3 * k[4] * r4 * dr2dt;
+        double da1dt = 2 * (x * dydt[j] + y * dxdt[j]);
+        dmxdt = dxdt[j] * cdist + x * dcdist_dt + k[2] * da1dt + k[3] * (dr2dt + 4 * x * dxdt[j]);
+        dmydt = dydt[j] * cdist + y * dcdist_dt + k[2] * (dr2dt + 4 * y * dydt[j]) + k[3] * da1dt;
+      }
+      dpdt[j] = cam.fx * dmxdt;
+      dpdt[3 + j] = cam.fy * dmydt;
     }
   }
   if (dpdr) {
@@ -301,8 +346,16 @@ __device__ inline void gm_project_point(const double R[9], const double* dRdr, c
     for (int j = 0; j < 3; j++) {
       double dxdr = z * (dx0dr[j] - x * dz0dr[j]);
       double dydr = z * (dy0dr[j] - y * dz0dr[j]);
-      dpdr[j] = cam.fx * dxdr;
-      dpdr[3 + j] = cam.fy * dydr;
+      double dmxdr = dxdr, dmydr = dydr;
+      if (cam.dist) {
+        double dr2dr = 2 * x * dxdr + 2 * y * dydr;
+        double dcdist_dr = (k[0] + 2 * k[1] * r2 + 3 * k[4] * r4) * dr2dr;
+        double da1dr = 2 * (x * dydr + y * dxdr);
+        dmxdr = dxdr * cdist + x * dcdist_dr + k[2] * da1dr + k[3] * (dr2dr + 4 * x * dxdr);
+        dmydr = dydr * cdist + y * dcdist_dr + k[2] * (dr2dr + 4 * y * dydr) + k[3] * da1dr;
+      }
+      dpdr[j] = cam.fx * dmxdr;
+      dpdr[3 + j] = cam.fy * dmydr;
     }
   }
 }
@@ -456,11 +509,11 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
   const int n = EP_N;
   EpnpState e;
   e.fu = cam.fx; e.fv = cam.fy; e.uc = cam.cx; e.vc = cam.cy;
-  double ifx = 1. / cam.fx, ify = 1. / cam.fy;
   for (int i = 0; i < n; i++) {
     e.pws[3 * i] = obj[3 * i]; e.pws[3 * i + 1] = obj[3 * i + 1]; e.pws[3 * i + 2] = obj[3 * i + 2];
-    float xn = (float)(((double)img[2 * i] - cam.cx) * ifx);
-    float yn = (float)(((double)img[2 * i + 1] - cam.cy) * ify);
+    double xu, yu;
+    gm_undistort_point(cam, (double)img[2 * i], (double)img[2 * i + 1], xu, yu);
+    float xn = (float)xu, yn = (float)yu;
     e.us[2 * i] = xn * e.fu + e.uc;
     e.us[2 * i + 1] = yn * e.fv + e.vc;
   }

@@ -209,8 +209,8 @@ int geom_ransac_h(mvo_ctx* ctx, int nslots, const float* p1, const float* p2, co
                   u8* mask, double* model, int* result, hipStream_t st);
 int geom_ransac_f(mvo_ctx* ctx, int nslots, const float* p1, const float* p2, const int* d_n, double thr, int max_iters, double conf,
                   u8* mask, double* model, int* result, hipStream_t st);
-int geom_pnp(mvo_ctx* ctx, int nslots, const float* obj, const float* img, const int* d_n, const double K[9], int iters, float reproj,
-             double conf, u8* mask, double* model, int* result, int* inl, double* pose, hipStream_t st);
+int geom_pnp(mvo_ctx* ctx, int nslots, const float* obj, const float* img, const int* d_n, const double K[9], const double* dist5, int iters,
+             float reproj, double conf, u8* mask, double* model, int* result, int* inl, double* pose, hipStream_t st);
 int geom_triangulate_matches(mvo_ctx* ctx, int nslots, int max_matches, const mvo_match* matches, const int* n_matches,
                              const float* kf_xy, const float* cur_xy, const double* kf_pose, const double* cur_pose,
                              const int* pnp_result, const double K[9], float* X3, u8* valid);

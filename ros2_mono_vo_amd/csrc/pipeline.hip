@@ -529,7 +529,7 @@ extern "C" int mvo_batch_step(mvo_ctx* ctx, int frame_idx, unsigned stages, mvo_
   if (do_pnp) {
     MVO_HIP(hipStreamWaitEvent(p->s_pnp, p->ev_lk, 0));
     { ProfScope ps(ctx, "pnp", p->s_pnp);
-      geom_pnp(ctx, B, p->d_cur_lm, p->d_cur_pts, p->d_ncur, p->K, 100, 8.0f, 0.99, g->d_mask, g->d_model, g->d_result, g->d_inl, g->d_pose,
+      geom_pnp(ctx, B, p->d_cur_lm, p->d_cur_pts, p->d_ncur, p->K, p->dist, 100, 8.0f, 0.99, g->d_mask, g->d_model, g->d_result, g->d_inl, g->d_pose,
                p->s_pnp); }
     MVO_HIP(hipMemcpyAsync(hr, g->d_result, (size_t)B * 8 * sizeof(int), hipMemcpyDeviceToHost, p->s_pnp));
     MVO_HIP(hipMemcpyAsync(hp, g->d_pose, (size_t)B * 8 * sizeof(double), hipMemcpyDeviceToHost, p->s_pnp));

@@ -77,6 +77,40 @@ def test_pnp_ransac(ctx720, P, planar):
     assert np.abs(O.rodrigues(r) - Rgt).max() < 2e-3 and np.abs(t - sc["t"]).max() < 5e-2
 
 
+def _distort(sc, d):
+    """Image points of the scene re-generated through the plumb-bob model d = (k1, k2, p1, p2, k3)."""
+    K = sc["K"]
+    x = (sc["p2"][:, 0].astype(np.float64) - K[0, 2]) / K[0, 0]
+    y = (sc["p2"][:, 1].astype(np.float64) - K[1, 2]) / K[1, 1]
+    k1, k2, p1, p2, k3 = d
+    r2 = x * x + y * y
+    cd = 1 + k1 * r2 + k2 * r2 ** 2 + k3 * r2 ** 3
+    xd = x * cd + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+    yd = y * cd + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+    return np.stack([xd * K[0, 0] + K[0, 2], yd * K[1, 1] + K[1, 2]], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("P,planar", [(300, False), (2000, False), (1000, True)])
+def test_pnp_ransac_with_distortion(ctx720, P, planar):
+    """solvePnPRansac with CameraInfo-style plumb-bob distortion (undistortPoints in the EPnP kernel and the DLT init,
+    distorted projectPoints in the RANSAC error and the LM refine)."""
+    sc = scene(P, planar)
+    d = np.array([-0.28, 0.07, 0.0007, -0.0004, 0.01])
+    img = _distort(sc, d)
+    ok, r, t, idx = ctx720.solve_pnp_ransac(sc["X"], img, sc["K"], d)
+    rc, orv, otv, oidx, st = O.solve_pnp_ransac(sc["X"], img, sc["K"], d)
+    assert ok and rc == 1
+    assert np.array_equal(idx, oidx)
+    tol = 1e-9
+    assert np.abs(r - orv).max() <= tol * max(1.0, np.abs(orv).max())
+    assert np.abs(t - otv).max() <= tol * max(1.0, np.abs(otv).max())
+    assert np.abs(O.rodrigues(r) - sc["R"]).max() < 2e-3 and np.abs(t - sc["t"]).max() < 5e-2
+    assert len(idx) > 0.7 * P
+    # ignoring the distortion on the same data must do visibly worse (the model is really exercised)
+    ok0, r0, t0, idx0 = ctx720.solve_pnp_ransac(sc["X"], img, sc["K"])
+    assert (not ok0) or len(idx0) < len(idx) or np.abs(t0 - sc["t"]).max() > np.abs(t - sc["t"]).max()
+
+
 def test_triangulate_bitexact(ctx720):
     sc = scene(2000)
     K = sc["K"]
