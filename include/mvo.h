@@ -132,7 +132,9 @@ int mvo_pyrdown(mvo_ctx* ctx, const uint8_t* src, int w, int h, int stride, uint
  * discards H).  Returns MVO_E_DEGENERATE with an all-zero mask when no model is found. */
 int mvo_find_homography_ransac(mvo_ctx* ctx, const float* p1, const float* p2, int n, double thr,
                                int max_iters, double confidence, uint8_t* mask, double H[9], int* n_inliers);
-/* cv::findFundamentalMat(p1, p2, FM_RANSAC, thr, confidence, mask) (7-point, max_iters 1000). */
+/* cv::findFundamentalMat(p1, p2, FM_RANSAC, thr, confidence, mask) (7-point, max_iters 1000).  As in OpenCV: n < 7 ->
+ * MVO_E_DEGENERATE (empty result), n == 7 -> the direct 7-point solution, 8 <= n < 15 -> LMedS (300 iterations, thr
+ * unused), n >= 15 -> RANSAC. */
 int mvo_find_fundamental_ransac(mvo_ctx* ctx, const float* p1, const float* p2, int n, double thr,
                                 double confidence, int max_iters, uint8_t* mask, double F[9],
                                 int* n_inliers);

@@ -240,8 +240,10 @@ extern "C" int orc_find_fundamental_ransac(const float* p1, const float* p2, int
   } else {
     if (thr <= 0) thr = 3;
     if (confidence < DBL_EPSILON || confidence > 1 - DBL_EPSILON) confidence = 0.99;
-    if (n < 15) return -2;  // LMedS branch (8 <= n < 15): not restated
-    ok = ransac_run(cb, p1, p2, n, 7, thr, confidence, max_iters, F, mask, &st);
+    // fundam.cpp: FM_RANSAC needs >= 15 points, below that findFundamentalMat silently switches to LMedS
+    // (createLMeDSPointSetRegistrator(cb, 7, confidence), default maxIters 1000)
+    if (n >= 15) ok = ransac_run(cb, p1, p2, n, 7, thr, confidence, max_iters, F, mask, &st);
+    else ok = lmeds_run(cb, p1, p2, n, 7, confidence, 1000, F, mask, &st);
   }
   if (stats) { stats[0] = st.iters_run; stats[1] = st.niters_final; stats[2] = st.hyp_models; }
   if (!ok) { memset(mask, 0, n); return 0; }

@@ -118,4 +118,75 @@ static inline bool ransac_run(const RansacCbT<T>& cb, const T* m1, const T* m2, 
   return false;
 }
 
+// LMeDSPointSetRegistrator::run (ptsetreg.cpp): fixed iteration count from the assumed outlier ratio 0.45, the model
+// with the smallest MEDIAN error wins (strictly smaller), then inliers = err <= sigma^2 with
+// sigma = 2.5 * 1.4826 * (1 + 5 / (count - modelPoints)) * sqrt(minMedian), floored at 0.001.
+// OpenCV takes the median as element count/2 after std::nth_element over the float bits: an order statistic,
+// so any selection gives the same value.
+template <typename T>
+static inline bool lmeds_run(const RansacCbT<T>& cb, const T* m1, const T* m2, int count, int modelPoints, double confidence,
+                             int maxIters, double* bestModel, unsigned char* bestMaskOut, RansacStats* stats = nullptr) {
+  const double outlierRatio = 0.45;
+  double minMedian = DBL_MAX;
+  RNG rng((uint64_t)-1);
+  if (count < modelPoints) return false;
+  std::vector<float> err(count), srt(count);
+  std::vector<double> model((size_t)cb.max_models * cb.model_size);
+  if (count == modelPoints) {
+    if (cb.run_kernel(m1, m2, count, model.data()) <= 0) return false;
+    memcpy(bestModel, model.data(), sizeof(double) * cb.model_size);
+    memset(bestMaskOut, 1, count);
+    return true;
+  }
+  int niters = ransac_update_num_iters(confidence, outlierRatio, modelPoints, maxIters);
+  niters = std::max(niters, 3);
+  std::vector<T> ms1((size_t)modelPoints * cb.d1), ms2((size_t)modelPoints * cb.d2);
+  std::vector<int> idx(modelPoints);
+  int iter;
+  for (iter = 0; iter < niters; iter++) {
+    bool found = false;
+    for (int attempt = 0; attempt < 10000; ++attempt) {
+      int i;
+      for (i = 0; i < modelPoints; ++i) {
+        int idx_i;
+        for (idx_i = rng.uniform(0, count); std::find(idx.begin(), idx.begin() + i, idx_i) != idx.begin() + i;
+             idx_i = rng.uniform(0, count)) {}
+        idx[i] = idx_i;
+        for (int k = 0; k < cb.d1; k++) ms1[i * cb.d1 + k] = m1[(size_t)idx_i * cb.d1 + k];
+        for (int k = 0; k < cb.d2; k++) ms2[i * cb.d2 + k] = m2[(size_t)idx_i * cb.d2 + k];
+      }
+      if (cb.check_subset(ms1.data(), ms2.data(), i)) { found = true; break; }
+    }
+    if (!found) {
+      if (iter == 0) return false;
+      break;
+    }
+    int nmodels = cb.run_kernel(ms1.data(), ms2.data(), modelPoints, model.data());
+    if (nmodels <= 0) continue;
+    for (int i = 0; i < nmodels; i++) {
+      const double* model_i = model.data() + (size_t)i * cb.model_size;
+      cb.compute_error(m1, m2, count, model_i, err.data());
+      srt = err;
+      std::nth_element(srt.begin(), srt.begin() + count / 2, srt.end());
+      double median = srt[count / 2];
+      if (stats) stats->hyp_models++;
+      if (median < minMedian) {
+        minMedian = median;
+        memcpy(bestModel, model_i, sizeof(double) * cb.model_size);
+      }
+    }
+  }
+  if (stats) { stats->iters_run = iter; stats->niters_final = niters; }
+  if (minMedian < DBL_MAX) {
+    double sigma = 2.5 * 1.4826 * (1 + 5. / (count - modelPoints)) * std::sqrt(minMedian);
+    sigma = std::max(sigma, 0.001);
+    cb.compute_error(m1, m2, count, bestModel, err.data());
+    const float t = (float)(sigma * sigma);
+    int good = 0;
+    for (int k = 0; k < count; k++) { int f = err[k] <= t; bestMaskOut[k] = (unsigned char)f; good += f; }
+    return good >= modelPoints;
+  }
+  return false;
+}
+
 }  // namespace orc

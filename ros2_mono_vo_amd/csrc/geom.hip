@@ -74,6 +74,7 @@ __global__ __launch_bounds__(RS_T, RS_WAVES_PER_EU) void ransac_kernel(RansacArg
   __shared__ int s_wpass[RS_NW];
   __shared__ unsigned long long s_wmask[RS_NW];
   __shared__ unsigned long long s_rng;
+  __shared__ double s_minmed;
 
   const int slot = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int count = min(max(A.n[slot], 0), A.cap);
@@ -89,9 +90,14 @@ __global__ __launch_bounds__(RS_T, RS_WAVES_PER_EU) void ransac_kernel(RansacArg
     if (tid == 0) { result[0] = 0; result[1] = 0; result[2] = 0; result[3] = 0; result[4] = 0; }
     return;
   }
+  // LMeDSPointSetRegistrator instead of RANSAC (findFundamentalMat below 15 points): fixed iteration count from the
+  // assumed outlier ratio 0.45, smallest median error wins, inliers by the robust sigma.  Same sampling machinery.
+  const bool lmeds = M::LMEDS_BELOW > 0 && count > M::MP && count < M::LMEDS_BELOW;
   if (tid == 0) {
     s_rng = 0xFFFFFFFFFFFFFFFFULL;
     s_ctl[1] = 0; s_ctl[2] = 0; s_ctl[3] = 0; s_ctl[4] = A.max_iters > 1 ? A.max_iters : 1; s_ctl[5] = 0; s_ctl[6] = 0; s_ctl[7] = 0;
+    if (lmeds) { int ni = gl_ransac_update_num_iters(A.conf, 0.45, M::MP, 1000); s_ctl[4] = ni > 3 ? ni : 3; }
+    s_minmed = DBL_MAX;
   }
   __syncthreads();
 
@@ -211,7 +217,24 @@ __global__ __launch_bounds__(RS_T, RS_WAVES_PER_EU) void ransac_kernel(RansacArg
     // ---- 4. scoring: hypothesis = tid % RS_CH, point partition = tid / RS_CH; integer inlier counts ------------
     {
       const int parts = RS_T / ch, hyp = tid % ch, part = tid / ch;
-      if (hyp < nsolve) {
+      if (lmeds) {
+        if (part == 0 && hyp < nsolve) {
+          const int nmh = s_nmodels[hyp];
+          for (int q = 0; q < nmh; q++) {
+            typename M::Scorer sc;
+            sc.init(A.P, &s_models[hyp][q][0]);
+            // median = element count/2 of the sorted errors (count < 15: insertion sort in registers / private memory)
+            float e[16];
+            for (int i = 0; i < count; i++) {
+              float v = sc.err(m1 + (size_t)i * M::PT1, m2 + (size_t)i * M::PT2);
+              int k = i;
+              while (k > 0 && e[k - 1] > v) { e[k] = e[k - 1]; --k; }
+              e[k] = v;
+            }
+            s_cnt[hyp][q] = __float_as_int(e[count / 2]);
+          }
+        }
+      } else if (hyp < nsolve) {
         const int nmh = s_nmodels[hyp];
         for (int q = 0; q < nmh; q++) {
           typename M::Scorer sc;
@@ -232,7 +255,13 @@ __global__ __launch_bounds__(RS_T, RS_WAVES_PER_EU) void ransac_kernel(RansacArg
         for (int q = 0; q < nmh; q++) {
           int good = s_cnt[h][q];
           scored++;
-          if (good > max(maxGood, M::MP - 1)) {
+          if (lmeds) {
+            const double median = (double)__int_as_float(good);
+            if (median < s_minmed) {
+              s_minmed = median;
+              for (int k = 0; k < M::MS; k++) s_best[k] = s_models[h][q][k];
+            }
+          } else if (good > max(maxGood, M::MP - 1)) {
             for (int k = 0; k < M::MS; k++) s_best[k] = s_models[h][q][k];
             maxGood = good;
             niters = gl_ransac_update_num_iters(A.conf, (double)(count - good) / count, M::MP, niters);
@@ -247,6 +276,32 @@ __global__ __launch_bounds__(RS_T, RS_WAVES_PER_EU) void ransac_kernel(RansacArg
     if (s_ctl[1]) break;
   }
   // ---- consensus mask of the winning model ---------------------------------------------------------------------
+  if (lmeds) {
+    const double minMedian = s_minmed;
+    if (minMedian < DBL_MAX) {
+      double sigma = 2.5 * 1.4826 * (1 + 5. / (count - M::MP)) * sqrt(minMedian);
+      sigma = sigma > 0.001 ? sigma : 0.001;
+      const float ts = (float)(sigma * sigma);
+      typename M::Scorer sc;
+      sc.init(A.P, s_best);
+      int good = 0;
+      for (int i = tid; i < count; i += RS_T) {
+        int f = sc.err(m1 + (size_t)i * M::PT1, m2 + (size_t)i * M::PT2) <= ts ? 1 : 0;
+        mask[i] = (u8)f;
+        good += f;
+      }
+      if (good) atomicAdd(&s_ctl[2], good);
+      if (tid < M::MS) out_model[tid] = s_best[tid];
+      __syncthreads();
+      good = s_ctl[2];
+      if (good < M::MP) for (int i = tid; i < count; i += RS_T) mask[i] = 0;   // findFundamentalMat returns an empty Mat
+      if (tid == 0) { result[0] = good >= M::MP; result[1] = good; result[2] = s_ctl[3]; result[3] = s_ctl[4]; result[4] = s_ctl[7]; }
+    } else {
+      for (int i = tid; i < count; i += RS_T) mask[i] = 0;
+      if (tid == 0) { result[0] = 0; result[1] = 0; result[2] = s_ctl[3]; result[3] = s_ctl[4]; result[4] = s_ctl[7]; }
+    }
+    return;
+  }
   const int maxGood = s_ctl[2];
   if (maxGood > 0) {
     typename M::Scorer sc;
@@ -927,7 +982,6 @@ extern "C" int mvo_find_fundamental_ransac(mvo_ctx* ctx, const float* p1, const 
   if (!ctx || !p1 || !p2 || !mask || n < 0) return MVO_E_ARG;
   if (n_inliers) *n_inliers = 0;
   if (n < 7) return MVO_E_DEGENERATE;  // OpenCV returns an empty Mat, mask untouched
-  if (n > 7 && n < 15) { ctx->set_error("findFundamentalMat LMedS branch (8 <= n < 15) is not built"); return MVO_E_ARG; }
   if (thr <= 0) thr = 3;
   if (confidence < DBL_EPSILON || confidence > 1 - DBL_EPSILON) confidence = 0.99;
   GeomState* g = ctx->geom;

@@ -77,6 +77,29 @@ def test_pnp_ransac(ctx720, P, planar):
     assert np.abs(O.rodrigues(r) - Rgt).max() < 2e-3 and np.abs(t - sc["t"]).max() < 5e-2
 
 
+def test_fundamental_lmeds_branch(ctx720):
+    """findFundamentalMat(FM_RANSAC) with 8..14 points runs LMedS (fundam.cpp): 300 fixed iterations, least median.
+    With 14 points the median (element 7 of the sorted errors) is a non-sample point's residual and the result is
+    reproducible: masks must match the oracle.  With 8..13 points the median is one of the seven sample points'
+    own residuals, i.e. rounding noise of the 7-point solver (~1e-25): which sample wins is decided by the last bits
+    of libm in OpenCV itself, so only the contract is checked there (a model, at least 7 inliers)."""
+    from ros2_mono_vo_amd import synth
+    for seed in range(1, 9):
+        sc = synth.gen_scene(14, 1400 + seed, outlier_frac=0.2)
+        ok, mask, F, ni = ctx720.find_fundamental_ransac(sc["p1"], sc["p2"], 1.0, 0.99, 1000)
+        r, omask, oF, st = O.find_fundamental_ransac(sc["p1"], sc["p2"], 1.0, 0.99, 1000)
+        assert st[0] == 300                          # RANSACUpdateNumIters(0.99, 0.45, 7, 1000)
+        assert ok == (r > 0), seed
+        assert np.array_equal(mask, omask), seed
+        if ok:
+            assert ni == r and np.abs(F - oF).max() <= 1e-9 * max(1.0, np.abs(oF).max())
+    for n in range(8, 14):
+        sc = synth.gen_scene(n, 100 * n + 1, outlier_frac=0.2)
+        ok, mask, F, ni = ctx720.find_fundamental_ransac(sc["p1"], sc["p2"], 1.0, 0.99, 1000)
+        r, omask, oF, st = O.find_fundamental_ransac(sc["p1"], sc["p2"], 1.0, 0.99, 1000)
+        assert ok and r > 0 and ni >= 7 and mask.sum() == ni and st[0] == 300
+
+
 def _distort(sc, d):
     """Image points of the scene re-generated through the plumb-bob model d = (k1, k2, p1, p2, k3)."""
     K = sc["K"]
