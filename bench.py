@@ -41,12 +41,13 @@ def planar_landmarks(K, z=10.0):
     return f
 
 
-def cpu_baseline(streams, K, nfeatures, n_frames):
-    """The oracle (CPU restatement, 1 thread) on a bounded sample of the same workload: stream 0,
-    `n_frames` consecutive full steps (tests/pipeline_ref.py: the same stage list and data flow as
+def cpu_baseline(seed, w, h, K, nfeatures, n_frames):
+    """The oracle (CPU restatement, 1 thread) on a bounded sample of the same workload: the first rank's stream 0
+    continued for `n_frames` consecutive full steps (tests/pipeline_ref.py: the same stage list and data flow as
     mvo_batch_step).  Test infrastructure used as the baseline only — never on the product path."""
     from pipeline_ref import StreamRef
-    fr = streams[0]
+    from ros2_mono_vo_amd import synth
+    fr = synth.gen_stream(w, h, seed, n_frames + 1)
     ref = StreamRef(K, nfeatures)
     ref.seed(fr[0], planar_landmarks(K))
     t0 = time.perf_counter()
@@ -69,7 +70,7 @@ def main():
     ap.add_argument("--nfeatures", type=int, default=2000)
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic streams generated per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=10)
+    ap.add_argument("--cpu-frames", type=int, default=50, help="consecutive oracle steps timed for cpu_baseline (~0.2 s each)")
     ap.add_argument("--stages", type=lambda v: int(v, 0), default=None,
                     help="diagnostic: MVO_STAGE_* mask to run instead of the full step (the line then lists stages_missing)")
     args = ap.parse_args()
@@ -186,7 +187,7 @@ def main():
             "stage_ms": prof,
         }
         if not args.no_cpu_baseline:
-            fps, nfr = cpu_baseline(streams, Kmat, args.nfeatures, args.cpu_frames)
+            fps, nfr = cpu_baseline(0x5EED0003 + 1, W, H, Kmat, args.nfeatures, args.cpu_frames)
             line["cpu_baseline"] = {"value": round(fps, 3), "unit": "frames/s", "cores": 1, "kind": "port",
                                     "sample": f"oracle (CPU restatement of OpenCV-4.6 semantics, not OpenCV), stream 0, "
                                               f"{nfr} consecutive full steps (same stage list and data flow), 1 thread"}

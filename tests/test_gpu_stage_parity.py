@@ -107,6 +107,22 @@ def test_orb_bitexact_720(ctx720, frames720):
     _check_orb(ctx720, frames720[0], 2000)
 
 
+def test_orb_and_lk_bitexact_1080_c4():
+    """BASELINE config C4 geometry: 1920x1080, 4000 ORB features (bigger LDS source tiles in the resize, more levels
+    above the edge band), plus LK on the same frames; odd sizes exercise the tile borders."""
+    from ros2_mono_vo_amd import Context
+    fr = synth.gen_stream(1920, 1080, 0x5EED0004, 2)
+    with Context(max_width=1920, max_height=1080, nfeatures=4000, max_points=8192) as ctx:
+        _check_orb(ctx, fr[0], 4000)
+        k, _ = O.orb_detect_and_compute(fr[0], 4000)
+        pts = np.stack([k["x"], k["y"]], 1)[::4]
+        _check_lk(ctx, fr[0], fr[1], pts)
+        odd = np.ascontiguousarray(fr[1][:1013, :1801])
+        gk, gd = ctx.orb_detect_and_compute(odd)
+        ok, od = O.orb_detect_and_compute(odd, 4000)
+        assert len(gk) == len(ok) and np.array_equal(gk["x"], ok["x"]) and np.array_equal(gk["y"], ok["y"]) and np.array_equal(gd, od)
+
+
 def test_orb_bgr_input(ctx480, frames480):
     g = frames480[1]
     bgr = np.stack([g, g, g], -1)
