@@ -125,8 +125,11 @@ def main():
     t0 = time.perf_counter()
     lk_points = 0
     last = None
+    step_ms = []
     for k in range(K):
-        last = ctx.batch_step(1 + Wm + k, stages)
+        ts = time.perf_counter()
+        last = ctx.batch_step(1 + Wm + k, stages)   # synchronous: returns when the step's results are on the host
+        step_ms.append(round((time.perf_counter() - ts) * 1e3, 3))
         lk_points += sum(r.n_prev for r in last)
     ctx.sync()
     torch.cuda.synchronize()
@@ -185,6 +188,7 @@ def main():
                          "valu_instructions_per_point": valu.get("valu_instructions_per_point"),
                          "valu_busy_frac_of_simd_time": valu.get("valu_busy_fraction_of_simd_time_at_2.4GHz")},
             "stage_ms": prof,
+            "step_ms": step_ms,
         }
         if not args.no_cpu_baseline:
             fps, nfr = cpu_baseline(0x5EED0003 + 1, W, H, Kmat, args.nfeatures, args.cpu_frames)
