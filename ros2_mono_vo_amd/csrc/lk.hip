@@ -20,37 +20,64 @@
 // ---------------------------------------------------------------------------------------------------
 #define PD_TW 64
 #define PD_TH 16
-#define PD_SW (2 * PD_TW + 3)
-#define PD_SH (2 * PD_TH + 3)
+#define PD_SR (2 * PD_TH + 3)   // source tile rows
+#define PD_SD 35                // source tile pitch in dwords: 136 bytes (2*64 + 8, origin 2*dx0 - 4) + pad, odd
+#define PD_HD 33                // row-sum tile pitch in dwords (32 packed u16 pairs + pad)
+typedef unsigned short pd_us2 __attribute__((ext_vector_type(2)));
 
+// cv::pyrDown (5x5 [1 4 6 4 1]^2 / 256, BORDER_REFLECT_101): source tile by dwords, horizontal taps with v_dot4_u32_u8
+// (two outputs per item), vertical taps on packed u16 pairs (the 16 * 4080 maximum fits 16 bits), (v + 128) >> 8.
 __global__ __launch_bounds__(256) void pyrdown_kernel(ImgSet src, ImgSet dst, TileGrid tg) {
-  __shared__ u8 s_src[PD_SH][PD_SW + 1];
-  __shared__ unsigned short s_h[PD_SH][PD_TW];
+  __shared__ unsigned s_src[PD_SR * PD_SD];
+  __shared__ unsigned s_h[PD_SR * PD_HD];
   int bx, by, bz;
   if (!xcd_tile(tg, bx, by, bz)) return;
   const u8* sp = src.slot(bz);
   u8* dp = dst.slot(bz);
-  int dx0 = bx * PD_TW, dy0 = by * PD_TH;
-  int sx0 = 2 * dx0 - 2, sy0 = 2 * dy0 - 2;
-  for (int i = threadIdx.x; i < PD_SH * PD_SW; i += 256) {
-    int ty = i / PD_SW, tx = i - ty * PD_SW;
-    int sx = d_reflect101(sx0 + tx, src.w), sy = d_reflect101(sy0 + ty, src.h);
-    s_src[ty][tx] = sp[(size_t)sy * src.pitch + sx];
+  const int dx0 = bx * PD_TW, dy0 = by * PD_TH, tid = threadIdx.x;
+  const int sx0 = 2 * dx0 - 4, sy0 = 2 * dy0 - 2;   // tile origin (dword aligned in x)
+  const bool interior = sx0 >= 0 && sx0 + 136 <= src.w && sy0 >= 0 && sy0 + PD_SR <= src.h;
+  if (interior) {
+    for (int i = tid; i < PD_SR * 34; i += 256) {
+      const int ty = __umul24(i, 1928) >> 16, k = i - ty * 34;   // i / 34 for i < 2^12
+      s_src[ty * PD_SD + k] = *(const unsigned*)(sp + (size_t)__umul24(sy0 + ty, src.pitch) + sx0 + 4 * k);
+    }
+  } else {
+    u8* sb = (u8*)s_src;
+    for (int i = tid; i < PD_SR * 136; i += 256) {
+      const int ty = i / 136, tx = i - ty * 136;
+      const int sx = d_reflect101(sx0 + tx, src.w), sy = d_reflect101(sy0 + ty, src.h);
+      sb[ty * (PD_SD * 4) + tx] = sp[(size_t)__umul24(sy, src.pitch) + sx];
+    }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < PD_SH * PD_TW; i += 256) {
-    int ty = i / PD_TW, tx = i - ty * PD_TW;
-    const u8* r = &s_src[ty][2 * tx];
-    s_h[ty][tx] = (unsigned short)(r[2] * 6 + (r[1] + r[3]) * 4 + r[0] + r[4]);
+  // horizontal: item = (row, pair m) -> outputs 2m, 2m+1 from tile bytes 4m+2 .. 4m+8
+  for (int i = tid; i < PD_SR * 32; i += 256) {
+    const int ty = i >> 5, m = i & 31;
+    const unsigned* r = s_src + ty * PD_SD + m;
+    const unsigned d0 = r[0], d1 = r[1], d2 = r[2];
+    unsigned o0 = __builtin_amdgcn_udot4(d0, 0x04010000u, __builtin_amdgcn_udot4(d1, 0x00010406u, 0u, false), false);
+    unsigned o1 = __builtin_amdgcn_udot4(d1, 0x04060401u, d2 & 0xFFu, false);
+    s_h[ty * PD_HD + m] = o0 | (o1 << 16);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < PD_TH * PD_TW; i += 256) {
-    int ty = i / PD_TW, tx = i - ty * PD_TW;
-    int x = dx0 + tx, y = dy0 + ty;
+  // vertical: one item per thread = 4 outputs (two packed pairs) of one row
+  {
+    const int ty = tid >> 4, q = tid & 15;
+    const int x = dx0 + 4 * q, y = dy0 + ty;
     if (x < dst.w && y < dst.h) {
-      int v = s_h[2 * ty + 2][tx] * 6 + (s_h[2 * ty + 1][tx] + s_h[2 * ty + 3][tx]) * 4 + s_h[2 * ty][tx] +
-              s_h[2 * ty + 4][tx];
-      dp[(size_t)y * dst.pitch + x] = (u8)((v + 128) >> 8);
+      const unsigned* c = s_h + (2 * ty) * PD_HD + 2 * q;
+      unsigned out = 0;
+#pragma unroll
+      for (int half = 0; half < 2; half++) {
+        const pd_us2 h0 = __builtin_bit_cast(pd_us2, c[half]), h1 = __builtin_bit_cast(pd_us2, c[PD_HD + half]),
+                     h2 = __builtin_bit_cast(pd_us2, c[2 * PD_HD + half]), h3 = __builtin_bit_cast(pd_us2, c[3 * PD_HD + half]),
+                     h4 = __builtin_bit_cast(pd_us2, c[4 * PD_HD + half]);
+        const pd_us2 six = {6, 6}, four = {4, 4}, rnd = {128, 128};
+        pd_us2 v = h2 * six + (h1 + h3) * four + h0 + h4 + rnd;
+        out |= ((unsigned)(v.x >> 8) | ((unsigned)(v.y >> 8) << 8)) << (16 * half);
+      }
+      *(unsigned*)(dp + (size_t)__umul24(y, dst.pitch) + x) = out;   // x % 4 == 0, pitch % 64 == 0
     }
   }
 }
