@@ -225,6 +225,7 @@ __global__ __launch_bounds__(RS_T, RS_WAVES_PER_EU) void ransac_kernel(RansacArg
             sc.init(A.P, &s_models[hyp][q][0]);
             // median = element count/2 of the sorted errors (count < 15: insertion sort in registers / private memory)
             float e[16];
+#pragma unroll 1
             for (int i = 0; i < count; i++) {
               float v = sc.err(m1 + (size_t)i * M::PT1, m2 + (size_t)i * M::PT2);
               int k = i;
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(RS_T, RS_WAVES_PER_EU) void ransac_kernel(RansacArg
           typename M::Scorer sc;
           sc.init(A.P, &s_models[hyp][q][0]);
           int good = 0;
+#pragma unroll 1
           for (int i = part; i < count; i += parts) good += sc.err(m1 + (size_t)i * M::PT1, m2 + (size_t)i * M::PT2) <= t;
           atomicAdd(&s_cnt[hyp][q], good);
         }
@@ -285,6 +287,7 @@ __global__ __launch_bounds__(RS_T, RS_WAVES_PER_EU) void ransac_kernel(RansacArg
       typename M::Scorer sc;
       sc.init(A.P, s_best);
       int good = 0;
+#pragma unroll 1
       for (int i = tid; i < count; i += RS_T) {
         int f = sc.err(m1 + (size_t)i * M::PT1, m2 + (size_t)i * M::PT2) <= ts ? 1 : 0;
         mask[i] = (u8)f;
@@ -306,6 +309,7 @@ __global__ __launch_bounds__(RS_T, RS_WAVES_PER_EU) void ransac_kernel(RansacArg
   if (maxGood > 0) {
     typename M::Scorer sc;
     sc.init(A.P, s_best);
+#pragma unroll 1
     for (int i = tid; i < count; i += RS_T) mask[i] = sc.err(m1 + (size_t)i * M::PT1, m2 + (size_t)i * M::PT2) <= t ? 1 : 0;
     if (tid < M::MS) out_model[tid] = s_best[tid];
   } else {

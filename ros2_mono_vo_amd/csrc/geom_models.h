@@ -71,10 +71,15 @@ struct HModel {
       double X = (M[2 * i] - cMx) * sMx, Y = (M[2 * i + 1] - cMy) * sMy;
       double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
       double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
+      // rolled on purpose: fully unrolled, these loops alone take ~250 VGPRs and the wave then crowds out its SIMD
+#pragma unroll 1
       for (int j = 0; j < 9; j++)
+#pragma unroll 1
         for (int k = j; k < 9; k++) LtL[j * 9 + k] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
     }
+#pragma unroll 1
     for (int j = 0; j < 9; j++)
+#pragma unroll 1
       for (int k = 0; k < j; k++) LtL[j * 9 + k] = LtL[k * 9 + j];
     gl_jacobi_eigen(LtL, 9, W, V);
     double Htemp[9], H0[9];
@@ -587,32 +592,40 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
     if (gl_is_lds(ws)) gl_jacobi_svd12_lds((gl_lds_double*)mtm, (gl_lds_double*)(ws + 288), (gl_lds_double*)tv);
     else gl_jacobi_svd(mtm, 12, d, tv, 12, 12, 12);
   }
-  double l_6x10[60], rho[6];
+  // dv (4 x 6 x 3) and L_6x10 live in the workspace (the V block is free after the SVD) and their loops stay rolled:
+  // as register arrays they pushed this function to ~250 VGPRs
+  double* dvm = ws2;         // [4][6][3], dead once L is built
+  double* l_6x10 = ws2 + 72; // [6][10]; the small solves below use ws2[0, 61)
+  double rho[6];
   {
-    const double* v[4] = {ut + 12 * 11, ut + 12 * 10, ut + 12 * 9, ut + 12 * 8};
-    double dv[4][6][3];
+#pragma unroll 1
     for (int i = 0; i < 4; i++) {
+      const double* vi = ut + 12 * (11 - i);
       int a = 0, b = 1;
+#pragma unroll 1
       for (int j = 0; j < 6; j++) {
-        dv[i][j][0] = v[i][3 * a] - v[i][3 * b];
-        dv[i][j][1] = v[i][3 * a + 1] - v[i][3 * b + 1];
-        dv[i][j][2] = v[i][3 * a + 2] - v[i][3 * b + 2];
+        double* d = dvm + (i * 6 + j) * 3;
+        d[0] = vi[3 * a] - vi[3 * b];
+        d[1] = vi[3 * a + 1] - vi[3 * b + 1];
+        d[2] = vi[3 * a + 2] - vi[3 * b + 2];
         b++;
         if (b > 3) { a++; b = a + 1; }
       }
     }
+#pragma unroll 1
     for (int i = 0; i < 6; i++) {
       double* row = l_6x10 + 10 * i;
-      row[0] = ep_dot(dv[0][i], dv[0][i]);
-      row[1] = 2.0f * ep_dot(dv[0][i], dv[1][i]);
-      row[2] = ep_dot(dv[1][i], dv[1][i]);
-      row[3] = 2.0f * ep_dot(dv[0][i], dv[2][i]);
-      row[4] = 2.0f * ep_dot(dv[1][i], dv[2][i]);
-      row[5] = ep_dot(dv[2][i], dv[2][i]);
-      row[6] = 2.0f * ep_dot(dv[0][i], dv[3][i]);
-      row[7] = 2.0f * ep_dot(dv[1][i], dv[3][i]);
-      row[8] = 2.0f * ep_dot(dv[2][i], dv[3][i]);
-      row[9] = ep_dot(dv[3][i], dv[3][i]);
+      const double *d0 = dvm + (0 * 6 + i) * 3, *d1 = dvm + (1 * 6 + i) * 3, *d2 = dvm + (2 * 6 + i) * 3, *d3 = dvm + (3 * 6 + i) * 3;
+      row[0] = ep_dot(d0, d0);
+      row[1] = 2.0f * ep_dot(d0, d1);
+      row[2] = ep_dot(d1, d1);
+      row[3] = 2.0f * ep_dot(d0, d2);
+      row[4] = 2.0f * ep_dot(d1, d2);
+      row[5] = ep_dot(d2, d2);
+      row[6] = 2.0f * ep_dot(d0, d3);
+      row[7] = 2.0f * ep_dot(d1, d3);
+      row[8] = 2.0f * ep_dot(d2, d3);
+      row[9] = ep_dot(d3, d3);
     }
     rho[0] = ep_dist2(e.cws[0], e.cws[1]); rho[1] = ep_dist2(e.cws[0], e.cws[2]); rho[2] = ep_dist2(e.cws[0], e.cws[3]);
     rho[3] = ep_dist2(e.cws[1], e.cws[2]); rho[4] = ep_dist2(e.cws[1], e.cws[3]); rho[5] = ep_dist2(e.cws[2], e.cws[3]);
