@@ -51,3 +51,44 @@ def test_batch_step_matches_oracle_flow(B):
         # stage subsets: LK only keeps the survivors as tracks
         out = ctx.batch_step(STEPS, _lib.STAGE_LK)
         assert all(out[s].n_prev > 0 for s in range(B))
+
+
+def test_batch_with_empty_and_lost_streams():
+    """Ragged batch: one textured stream, one featureless stream (no key-points at all) and one stream whose
+    camera jumps to unrelated content (tracking lost: few LK survivors, PnP / H / F on almost nothing).  The
+    degenerate slots must neither crash nor disturb the healthy one, which has to match its solo oracle flow."""
+    W, H, NF, STEPS = 640, 480, 1000, 3
+    K = synth.default_K(W, H)
+    good = synth.gen_stream(W, H, 0x5EED0200, STEPS + 1)
+    flat = np.full((STEPS + 1, H, W), 93, np.uint8)
+    other = synth.gen_stream(W, H, 0x5EED0300, STEPS + 1)
+    lost = good.copy()
+    lost[2:] = other[2:]                     # frames 2.. show a different scene
+    streams = [good, flat, lost]
+    B = 3
+    with Context(max_width=W, max_height=H, batch=B, nfeatures=NF, max_points=4096, ring_frames=STEPS + 1) as ctx:
+        ctx.batch_set_intrinsics(K)
+        for s in range(B):
+            for f in range(STEPS + 1):
+                ctx.batch_preload_frame(s, f, streams[s][f])
+        nk = ctx.batch_seed(0)
+        assert nk[1] == 0 and nk[0] > 900 and nk[2] == nk[0]
+        ref = StreamRef(K, NF)
+        ref.seed(good[0], planar_landmarks(K))
+        for s in (0, 2):
+            ctx.batch_set_landmarks(s, ref.trk_lm)
+        for k in range(1, STEPS + 1):
+            out = ctx.batch_step(k, _lib.STAGE_ALL)
+            e = ref.step(good[k])
+            o = out[0]
+            for key in ("n_prev", "n_tracked", "n_keypoints", "n_matches", "n_pnp_inliers", "score_h", "score_f", "n_triangulated"):
+                assert getattr(o, key) == e[key], (k, key)
+            assert np.abs(np.array(o.rvec) - e["rvec"]).max() < 1e-6
+            z = out[1]                      # featureless: nothing anywhere, no pose
+            assert z.n_prev == 0 and z.n_tracked == 0 and z.n_keypoints == 0 and z.n_matches == 0 and not z.pnp_ok
+            assert z.score_h == 0 and z.score_f == 0 and z.n_triangulated == 0
+            l = out[2]
+            if k == 1:
+                assert l.n_tracked == o.n_tracked
+            else:
+                assert l.n_tracked < 0.5 * max(l.n_prev, 1) or l.n_pnp_inliers < 0.5 * max(l.n_tracked, 1)
