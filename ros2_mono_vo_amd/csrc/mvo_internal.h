@@ -126,10 +126,8 @@ struct OrbState {
   int kp_cap = 0;  // dense, whole batch
   int* d_sel = nullptr;  // selected candidate indices
   mvo_keypoint* d_kp = nullptr;
-  float* d_kang = nullptr;
   u8* d_desc = nullptr;
   char4* d_pattern = nullptr;
-  int* d_umax = nullptr;
   unsigned* d_icmask = nullptr;  // [16][9] byte masks of the IC-angle disc rows
   // pinned host mirrors
   int* h_counts = nullptr;  // [B][8] level counts + [B+1] candidate bases + [B+1] key-point bases

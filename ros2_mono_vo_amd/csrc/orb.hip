@@ -8,7 +8,7 @@
 //                         per-row survivor counts (atomics) for the compaction
 //   scan_rows/scan_slots  exclusive scans (rows -> levels -> slots) so candidates of the whole batch are
 //                         one dense array
-//   nms_rows_kernel<1>    edgeThreshold cull + ORDERED (row-major) emit of the non-zero map entries; one wavefront
+//   nms_rows_kernel    edgeThreshold cull + ORDERED (row-major) emit of the non-zero map entries; one wavefront
 //                         per image row, 4 pixels per lane, __ballot + popcount
 //   orb_select_kernel     (orb_select.hip) KeyPointsFilter::retainBest twice per level in libstdc++'s
 //                         nth_element/partition element order - that permutation IS OpenCV's key-point order -
@@ -388,9 +388,9 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// ordered compaction of the non-zero entries of the NMS map (row-major), 4 pixels per lane
+// ordered emit of the non-zero entries of the NMS map (row-major), 4 pixels per lane; the per-row counts come from
+// fast_nms_kernel and their exclusive scans from scan_rows / scan_slots
 // ---------------------------------------------------------------------------------------------------
-template <int EMIT>
 __global__ __launch_bounds__(256) void nms_rows_kernel(const u8* __restrict__ score, OrbGeom G, int* __restrict__ row_cnt,
                                                        const int* __restrict__ row_off,
                                                        const int* __restrict__ slot_base, int max_rows,
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void nms_rows_kernel(const u8* __restrict__ sc
   const int xlo = G.edge, xhi = w - G.edge;  // [xlo, xhi)
   int count = 0;
   int base = 0;
-  if (EMIT) base = slot_base[slot] + row_off[(size_t)slot * max_rows + row];
+  base = slot_base[slot] + row_off[(size_t)slot * max_rows + row];
   for (int xb = xlo & ~3; xb < xhi; xb += 256) {
     int x = xb + lane * 4;
     unsigned v = 0;
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void nms_rows_kernel(const u8* __restrict__ sc
     for (int j = 0; j < 4; j++)
       if ((v >> (8 * j)) & 0xFF) { if (j0 < 0) j0 = j; else j1 = j; }
     unsigned long long m0 = __ballot(j0 >= 0), m1 = __ballot(j1 >= 0);
-    if (EMIT && j0 >= 0) {
+    if (j0 >= 0) {
       unsigned long long below = (1ull << lane) - 1;
       int o = base + count + __popcll(m0 & below) + __popcll(m1 & below);
       if (o < cand_cap) {
@@ -438,7 +438,6 @@ __global__ __launch_bounds__(256) void nms_rows_kernel(const u8* __restrict__ sc
     }
     count += __popcll(m0) + __popcll(m1);
   }
-  if (!EMIT && lane == 0) row_cnt[(size_t)slot * max_rows + row] = count;
 }
 
 // one block per slot: exclusive scan of the row counts (rows of all levels in order), per-level totals.
@@ -738,7 +737,6 @@ int orb_state_create(mvo_ctx* ctx) {
   MVO_HIP(hipMalloc(&o->d_kp, (size_t)o->kp_cap * sizeof(mvo_keypoint)));
   MVO_HIP(hipMalloc(&o->d_desc, (size_t)o->kp_cap * 32));
   MVO_HIP(hipMalloc(&o->d_pattern, 256 * sizeof(char4)));
-  MVO_HIP(hipMalloc(&o->d_umax, 32 * sizeof(int)));
   {
     const int* src = ctx->cfg.orb_pattern ? ctx->cfg.orb_pattern : kOrbPattern31;
     char4 pat[256];
@@ -755,7 +753,6 @@ int orb_state_create(mvo_ctx* ctx) {
       umax[v] = v0;
       ++v0;
     }
-    MVO_HIP(hipMemcpy(o->d_umax, umax, sizeof(umax), hipMemcpyHostToDevice));
     // IC-angle row masks: row |dy| keeps bytes u + 16 of the 36-byte window x0-16 .. x0+19 with |u| <= umax[|dy|]
     unsigned icm[16 * 9];
     for (int v = 0; v < 16; v++)
@@ -783,7 +780,7 @@ void orb_state_destroy(mvo_ctx* ctx) {
   if (!o) return;
   void* dev[] = {o->d_pyr, o->d_score, o->d_blur, o->d_row_cnt, o->d_row_off, o->d_lvl_cnt, o->d_slot_tot,
                  o->d_slot_base, o->d_cx, o->d_cy, o->d_cs, o->d_cl, o->d_cslot, o->d_ch, o->d_sel, o->d_kp,
-                 o->d_desc, o->d_pattern, o->d_umax, o->d_wk, o->d_stl, o->d_str, o->d_kept, o->d_kp_base, o->d_rtab, o->d_icmask};
+                 o->d_desc, o->d_pattern, o->d_wk, o->d_stl, o->d_str, o->d_kept, o->d_kp_base, o->d_rtab, o->d_icmask};
   for (void* p : dev) (void)hipFree(p);
   void* hst[] = {o->h_counts, o->h_kp, o->h_desc};
   for (void* p : hst)
@@ -864,7 +861,7 @@ static int orb_detect_device(mvo_ctx* ctx, const OrbGeom& G, int nslots, hipEven
   hipLaunchKernelGGL(scan_slots_kernel, dim3(1), dim3(64), 0, st, o->d_slot_tot, o->d_slot_base, nslots);
   if (nrows > 0) {
     dim3 grid((nrows + 3) / 4, nslots);
-    hipLaunchKernelGGL(nms_rows_kernel<1>, grid, dim3(256), 0, st, o->d_score, G, o->d_row_cnt, o->d_row_off,
+    hipLaunchKernelGGL(nms_rows_kernel, grid, dim3(256), 0, st, o->d_score, G, o->d_row_cnt, o->d_row_off,
                        o->d_slot_base, o->max_rows, o->d_cx, o->d_cy, o->d_cs, o->d_cl, o->d_cslot, o->cand_cap);
   }
   return MVO_OK;
@@ -1017,7 +1014,7 @@ extern "C" int mvo_fast9_nms(mvo_ctx* ctx, const uint8_t* img, int w, int h, int
   hipLaunchKernelGGL(scan_rows_kernel, dim3(1), dim3(1024), 0, st, o->d_row_cnt, o->d_row_off, G, o->max_rows, o->d_lvl_cnt,
                      o->d_slot_tot);
   hipLaunchKernelGGL(scan_slots_kernel, dim3(1), dim3(64), 0, st, o->d_slot_tot, o->d_slot_base, 1);
-  hipLaunchKernelGGL(nms_rows_kernel<1>, g2, dim3(256), 0, st, o->d_score, G, o->d_row_cnt, o->d_row_off, o->d_slot_base,
+  hipLaunchKernelGGL(nms_rows_kernel, g2, dim3(256), 0, st, o->d_score, G, o->d_row_cnt, o->d_row_off, o->d_slot_base,
                      o->max_rows, o->d_cx, o->d_cy, o->d_cs, o->d_cl, o->d_cslot, o->cand_cap);
   int* hn = (int*)ctx->h_pin;
   MVO_HIP(hipMemcpyAsync(hn, o->d_slot_tot, sizeof(int), hipMemcpyDeviceToHost, st));
