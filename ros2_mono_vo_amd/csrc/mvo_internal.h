@@ -100,6 +100,8 @@ struct OrbState {
   u8* d_blur = nullptr;   // blurred pyramid, same layout
   int max_rows = 0;
   int* d_row_cnt = nullptr;   // [B][max_rows]
+  u8* d_seg_cnt = nullptr;    // [B][max_rows][seg_per_row] NMS survivors per 64-pixel row segment
+  int seg_per_row = 0;
   int* d_row_off = nullptr;   // [B][max_rows]  offset inside the slot's candidate range
   int* d_lvl_cnt = nullptr;   // [B][8]
   int* d_slot_tot = nullptr;  // [B]

@@ -4,12 +4,12 @@
 // Device pipeline, every launch covering all slots of the batch:
 //   resize_exact_kernel   8-level pyramid, INTER_LINEAR_EXACT 8.8 x 8.8 fixed point (level l from l-1), table driven
 //   fast_nms_kernel       FAST-9/16 + cornerScore + strict 3x3 NMS fused per 64x32 tile: packed 4-point pre-test,
-//                         ballot-compacted candidate list in LDS, full score for candidates only, dword stores,
-//                         per-row survivor counts (atomics) for the compaction
+//                         ballot-compacted candidate list in LDS, full score for candidates only; the survivors inside
+//                         the edge band leave as (x, score) records per 64-pixel row segment + segment / row counts
+//                         (no dense score map is written)
 //   scan_rows/scan_slots  exclusive scans (rows -> levels -> slots) so candidates of the whole batch are
 //                         one dense array
-//   nms_rows_kernel    edgeThreshold cull + ORDERED (row-major) emit of the non-zero map entries; one wavefront
-//                         per image row, 4 pixels per lane, __ballot + popcount
+//   nms_rows_kernel       ORDERED (row-major) emit of the records: half a wavefront per image row, one lane per segment
 //   orb_select_kernel     (orb_select.hip) KeyPointsFilter::retainBest twice per level in libstdc++'s
 //                         nth_element/partition element order - that permutation IS OpenCV's key-point order -
 //                         with the Harris responses of the first pass's survivors computed in between
@@ -247,6 +247,8 @@ struct FastArgs {
   int edge;      // the compaction scans rows [edge, h-edge) x columns [edge, w-edge): survivors there are counted per row
   int* row_cnt;  // [slots][max_rows], zeroed before the launch; this level's rows start at row_first
   int max_rows, row_first;
+  u8* seg_cnt;   // [slots][max_rows][seg_per_row], zeroed before the launch: survivors per 64-pixel row segment
+  int seg_per_row;
   TileGrid tg;
 };
 
@@ -265,14 +267,9 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs A) {
   const int w = A.w, h = A.h, pitch = A.pitch, lo = A.lo;
   const int x0 = bx * FT_W, y0 = by * FT_H;
   const int tid = threadIdx.x, lane = tid & 63;
-  // tiles that cannot contain a needed score: write zeros and leave
+  // tiles that cannot contain a needed score
   const bool dead = x0 + FT_W + 1 <= lo || x0 - 1 >= w - lo || y0 + FT_H + 1 <= lo || y0 - 1 >= h - lo;
-  if (dead) {
-    const int c4 = (tid & 15) * 4;
-    for (int row = tid >> 4; row < FT_H; row += 16)
-      if (y0 + row < h && x0 + c4 < pitch) *(unsigned*)(dp + (size_t)__umul24(y0 + row, pitch) + x0 + c4) = 0u;
-    return;
-  }
+  if (dead) return;  // seg_cnt / row_cnt are zeroed before the launch
   if (tid == 0) s_n = 0;
   // ---- phase 0: pixel tile rows y0-4 .. y0+35, columns x0-4 .. x0+67 ----------------------------------------------------
   const bool interior = x0 >= 4 && x0 + 68 <= w && y0 >= 4 && y0 + FT_H + 4 <= h;
@@ -371,72 +368,89 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs A) {
     const ft_s2 klo = (__builtin_bit_cast(ft_s2, nlo) - vlo) >> 15, khi = (__builtin_bit_cast(ft_s2, nhi) - vhi) >> 15;
     const unsigned olo = __builtin_bit_cast(unsigned, vlo) & __builtin_bit_cast(unsigned, klo);
     const unsigned ohi = __builtin_bit_cast(unsigned, vhi) & __builtin_bit_cast(unsigned, khi);
-    const unsigned out = __builtin_amdgcn_perm(ohi, olo, 0x06040200u);
-    if (gy < h && gx < pitch) *(unsigned*)(dp + (size_t)__umul24(gy, pitch) + gx) = out;
-    // survivors inside the compaction band, summed over the 16 lanes that share this row
-    int cnt = 0;
-    if (gy >= A.edge && gy < h - A.edge) {
+    unsigned out = __builtin_amdgcn_perm(ohi, olo, 0x06040200u);
+    // Survivors inside the compaction band go out as (x in tile, score) records at the head of this row segment's 64
+    // bytes of the score plane - strict NMS leaves at most 32 per 64 pixels - with their count in seg_cnt: the dense
+    // map is never written, and the emit pass reads counts and records only.
+    const bool row_in = gy >= A.edge && gy < h - A.edge;
 #pragma unroll
-      for (int j = 0; j < 4; j++) cnt += ((out >> (8 * j)) & 0xFFu) != 0 && gx + j >= A.edge && gx + j < w - A.edge;
-    }
-    cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x111, 0xf, 0xf, true);  // row_shr:1
-    cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x112, 0xf, 0xf, true);  // row_shr:2
+    for (int j = 0; j < 4; j++)
+      if (!row_in || gx + j < A.edge || gx + j >= w - A.edge) out &= ~(0xFFu << (8 * j));
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) cnt += ((out >> (8 * j)) & 0xFFu) != 0;
+    const int own = cnt;
+    cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x111, 0xf, 0xf, true);  // row_shr:1   inclusive prefix over the 16 lanes
+    cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x112, 0xf, 0xf, true);  // row_shr:2   that share this row segment
     cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x114, 0xf, 0xf, true);  // row_shr:4
     cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x118, 0xf, 0xf, true);  // row_shr:8
-    if ((tid & 15) == 15 && cnt > 0) atomicAdd(A.row_cnt + (size_t)bz * A.max_rows + A.row_first + (gy - A.edge), cnt);
+    if (own) {
+      unsigned short* rec = (unsigned short*)(dp + (size_t)__umul24(gy, pitch) + x0) + (cnt - own);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const unsigned sc = (out >> (8 * j)) & 0xFFu;
+        if (sc) *rec++ = (unsigned short)(((unsigned)(4 * (g - 1) + j) << 8) | sc);
+      }
+    }
+    if ((tid & 15) == 15 && cnt > 0) {
+      const size_t rowi = (size_t)bz * A.max_rows + A.row_first + (gy - A.edge);
+      A.seg_cnt[rowi * A.seg_per_row + bx] = (u8)cnt;
+      atomicAdd(A.row_cnt + rowi, cnt);
+    }
   }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// ordered emit of the non-zero entries of the NMS map (row-major), 4 pixels per lane; the per-row counts come from
-// fast_nms_kernel and their exclusive scans from scan_rows / scan_slots
+// ordered emit of the NMS survivors (row-major per level): one wavefront per image row, one lane per 64-pixel
+// segment; counts from seg_cnt, offsets from scan_rows / scan_slots, records from the head of each segment
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void nms_rows_kernel(const u8* __restrict__ score, OrbGeom G, int* __restrict__ row_cnt,
-                                                       const int* __restrict__ row_off,
-                                                       const int* __restrict__ slot_base, int max_rows,
-                                                       unsigned short* __restrict__ cx, unsigned short* __restrict__ cy,
-                                                       u8* __restrict__ cs, u8* __restrict__ cl, int* __restrict__ cslot,
-                                                       int cand_cap) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+// RPW rows per wavefront: 2 (one per 32-lane half) when a row has at most 32 segments, else 1.
+template <int RPW>
+__global__ __launch_bounds__(256) void nms_rows_kernel(const u8* __restrict__ score, const u8* __restrict__ seg_cnt, int seg_per_row,
+                                                       OrbGeom G, const int* __restrict__ row_off, const int* __restrict__ slot_base,
+                                                       int max_rows, unsigned short* __restrict__ cx, unsigned short* __restrict__ cy,
+                                                       u8* __restrict__ cs, u8* __restrict__ cl, int* __restrict__ cslot, int cand_cap) {
+  constexpr int LPR = 64 / RPW;  // lanes per row
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane & (LPR - 1);
   const int slot = blockIdx.y;
-  const int row = blockIdx.x * 4 + wave;
-  if (row >= G.row0[G.nlevels]) return;
+  const int row = (blockIdx.x * 4 + wave) * RPW + lane / LPR;
+  const bool live = row < G.row0[G.nlevels];
   int l = 0;
 #pragma unroll
   for (int k = 1; k < MVO_ORB_LEVELS; k++) l += (row >= G.row0[k]);
-  const int w = G.w[l], pitch = G.pitch[l];
+  l = live ? l : 0;
+  const int pitch = G.pitch[l];
   const int y = G.edge + (row - G.row0[l]);
-  const u8* sp = score + (size_t)slot * G.slot_stride + G.off[l] + (size_t)y * pitch;
-  const int xlo = G.edge, xhi = w - G.edge;  // [xlo, xhi)
-  int count = 0;
-  int base = 0;
-  base = slot_base[slot] + row_off[(size_t)slot * max_rows + row];
-  for (int xb = xlo & ~3; xb < xhi; xb += 256) {
-    int x = xb + lane * 4;
-    unsigned v = 0;
-    if (x < xhi) v = *(const unsigned*)(sp + x);
-    // mask bytes outside [xlo, xhi)
+  const int nseg = (G.w[l] + 63) >> 6;
+  const size_t rowi = (size_t)slot * max_rows + (live ? row : 0);
+  const int cnt = (live && sub < nseg) ? seg_cnt[rowi * seg_per_row + sub] : 0;
+  int incl = cnt;
 #pragma unroll
-    for (int j = 0; j < 4; j++)
-      if (x + j < xlo || x + j >= xhi) v &= ~(0xFFu << (8 * j));
-    // NMS survivors are never horizontally adjacent, so a dword holds at most 2 of them
-    int j0 = -1, j1 = -1;
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-      if ((v >> (8 * j)) & 0xFF) { if (j0 < 0) j0 = j; else j1 = j; }
-    unsigned long long m0 = __ballot(j0 >= 0), m1 = __ballot(j1 >= 0);
-    if (j0 >= 0) {
-      unsigned long long below = (1ull << lane) - 1;
-      int o = base + count + __popcll(m0 & below) + __popcll(m1 & below);
-      if (o < cand_cap) {
-        cx[o] = (unsigned short)(x + j0); cy[o] = (unsigned short)y; cs[o] = (u8)((v >> (8 * j0)) & 0xFF); cl[o] = (u8)l; cslot[o] = slot;
-      }
-      if (j1 >= 0 && o + 1 < cand_cap) {
-        cx[o + 1] = (unsigned short)(x + j1); cy[o + 1] = (unsigned short)y; cs[o + 1] = (u8)((v >> (8 * j1)) & 0xFF); cl[o + 1] = (u8)l;
-        cslot[o + 1] = slot;
-      }
-    }
-    count += __popcll(m0) + __popcll(m1);
+  for (int d = 1; d < LPR; d <<= 1) {
+    int t = __shfl_up(incl, d, LPR);
+    if (sub >= d) incl += t;
+  }
+  if (cnt == 0) return;
+  int o = slot_base[slot] + row_off[rowi] + incl - cnt;
+  const unsigned short* rec = (const unsigned short*)(score + (size_t)slot * G.slot_stride + G.off[l] + (size_t)y * pitch + sub * 64);
+  for (int k = 0; k < cnt; k++, o++) {
+    if (o >= cand_cap) break;
+    const unsigned r = rec[k];
+    cx[o] = (unsigned short)(sub * 64 + (r >> 8)); cy[o] = (unsigned short)y; cs[o] = (u8)(r & 0xFFu); cl[o] = (u8)l; cslot[o] = slot;
+  }
+}
+
+static void nms_rows_launch(mvo_ctx* ctx, const OrbGeom& G, int nrows, int nslots) {
+  OrbState* o = ctx->orb;
+  if (nrows <= 0) return;
+  if (o->seg_per_row <= 32) {
+    dim3 grid((nrows + 7) / 8, nslots);
+    hipLaunchKernelGGL(nms_rows_kernel<2>, grid, dim3(256), 0, ctx->stream, o->d_score, o->d_seg_cnt, o->seg_per_row, G, o->d_row_off,
+                       o->d_slot_base, o->max_rows, o->d_cx, o->d_cy, o->d_cs, o->d_cl, o->d_cslot, o->cand_cap);
+  } else {
+    dim3 grid((nrows + 3) / 4, nslots);
+    hipLaunchKernelGGL(nms_rows_kernel<1>, grid, dim3(256), 0, ctx->stream, o->d_score, o->d_seg_cnt, o->seg_per_row, G, o->d_row_off,
+                       o->d_slot_base, o->max_rows, o->d_cx, o->d_cy, o->d_cs, o->d_cl, o->d_cslot, o->cand_cap);
   }
 }
 
@@ -709,6 +723,9 @@ int orb_state_create(mvo_ctx* ctx) {
   MVO_HIP(hipMalloc(&o->d_score, tot));
   MVO_HIP(hipMalloc(&o->d_blur, tot));
   MVO_HIP(hipMalloc(&o->d_row_cnt, (size_t)ctx->B * o->max_rows * sizeof(int)));
+  o->seg_per_row = (ctx->maxw + 63) / 64;
+  if (o->seg_per_row > 64) { ctx->set_error("max_width above 4096 is not supported by the ORB emit pass"); return MVO_E_ARG; }
+  MVO_HIP(hipMalloc(&o->d_seg_cnt, (size_t)ctx->B * o->max_rows * o->seg_per_row));
   MVO_HIP(hipMalloc(&o->d_row_off, (size_t)ctx->B * o->max_rows * sizeof(int)));
   MVO_HIP(hipMalloc(&o->d_lvl_cnt, (size_t)ctx->B * MVO_ORB_LEVELS * sizeof(int)));
   MVO_HIP(hipMalloc(&o->d_slot_tot, (size_t)ctx->B * sizeof(int)));
@@ -778,7 +795,7 @@ int orb_state_create(mvo_ctx* ctx) {
 void orb_state_destroy(mvo_ctx* ctx) {
   OrbState* o = ctx->orb;
   if (!o) return;
-  void* dev[] = {o->d_pyr, o->d_score, o->d_blur, o->d_row_cnt, o->d_row_off, o->d_lvl_cnt, o->d_slot_tot,
+  void* dev[] = {o->d_pyr, o->d_score, o->d_blur, o->d_seg_cnt, o->d_row_cnt, o->d_row_off, o->d_lvl_cnt, o->d_slot_tot,
                  o->d_slot_base, o->d_cx, o->d_cy, o->d_cs, o->d_cl, o->d_cslot, o->d_ch, o->d_sel, o->d_kp,
                  o->d_desc, o->d_pattern, o->d_wk, o->d_stl, o->d_str, o->d_kept, o->d_kp_base, o->d_rtab, o->d_icmask};
   for (void* p : dev) (void)hipFree(p);
@@ -799,6 +816,7 @@ static void fast_nms_launch(mvo_ctx* ctx, const OrbGeom& G, int l, int nslots, i
   // a level with no compaction rows (smaller than the edge band) must not count anything
   A.edge = G.row0[l + 1] > G.row0[l] ? G.edge : (1 << 20);
   A.row_cnt = o->d_row_cnt; A.max_rows = o->max_rows; A.row_first = G.row0[l];
+  A.seg_cnt = o->d_seg_cnt; A.seg_per_row = o->seg_per_row;
   A.tg = TileGrid{(G.w[l] + FT_W - 1) / FT_W, (G.h[l] + FT_H - 1) / FT_H, nslots};
   hipLaunchKernelGGL(fast_nms_kernel, dim3(xcd_grid_blocks(A.tg)), dim3(256), 0, ctx->stream, A);
 }
@@ -854,16 +872,13 @@ static int orb_detect_device(mvo_ctx* ctx, const OrbGeom& G, int nslots, hipEven
   if (before_fast) MVO_HIP(hipStreamWaitEvent(st, before_fast, 0));
   // per-row survivor counts are accumulated by the FAST/NMS kernel itself (phase 3)
   MVO_HIP(hipMemsetAsync(o->d_row_cnt, 0, (size_t)nslots * o->max_rows * sizeof(int), st));
+  MVO_HIP(hipMemsetAsync(o->d_seg_cnt, 0, (size_t)nslots * o->max_rows * o->seg_per_row, st));
   for (int l = 0; l < G.nlevels; l++) fast_nms_launch(ctx, G, l, nslots, ctx->cfg.fast_threshold, std::max(3, G.edge - 1));
   int nrows = G.row0[G.nlevels];
   hipLaunchKernelGGL(scan_rows_kernel, dim3(nslots), dim3(1024), 0, st, o->d_row_cnt, o->d_row_off, G, o->max_rows,
                      o->d_lvl_cnt, o->d_slot_tot);
   hipLaunchKernelGGL(scan_slots_kernel, dim3(1), dim3(64), 0, st, o->d_slot_tot, o->d_slot_base, nslots);
-  if (nrows > 0) {
-    dim3 grid((nrows + 3) / 4, nslots);
-    hipLaunchKernelGGL(nms_rows_kernel, grid, dim3(256), 0, st, o->d_score, G, o->d_row_cnt, o->d_row_off,
-                       o->d_slot_base, o->max_rows, o->d_cx, o->d_cy, o->d_cs, o->d_cl, o->d_cslot, o->cand_cap);
-  }
+  nms_rows_launch(ctx, G, nrows, nslots);
   return MVO_OK;
 }
 
@@ -1008,14 +1023,13 @@ extern "C" int mvo_fast9_nms(mvo_ctx* ctx, const uint8_t* img, int w, int h, int
   G.row0[1] = (h <= 6 || w <= 6) ? 0 : h - 6;
   for (int l = 2; l <= MVO_ORB_LEVELS; l++) G.row0[l] = G.row0[1];
   MVO_HIP(hipMemsetAsync(o->d_row_cnt, 0, (size_t)o->max_rows * sizeof(int), st));
+  MVO_HIP(hipMemsetAsync(o->d_seg_cnt, 0, (size_t)o->max_rows * o->seg_per_row, st));
   fast_nms_launch(ctx, G, 0, 1, threshold, 3);
   int nrows = G.row0[1];
-  dim3 g2((nrows + 3) / 4, 1);
   hipLaunchKernelGGL(scan_rows_kernel, dim3(1), dim3(1024), 0, st, o->d_row_cnt, o->d_row_off, G, o->max_rows, o->d_lvl_cnt,
                      o->d_slot_tot);
   hipLaunchKernelGGL(scan_slots_kernel, dim3(1), dim3(64), 0, st, o->d_slot_tot, o->d_slot_base, 1);
-  hipLaunchKernelGGL(nms_rows_kernel, g2, dim3(256), 0, st, o->d_score, G, o->d_row_cnt, o->d_row_off, o->d_slot_base,
-                     o->max_rows, o->d_cx, o->d_cy, o->d_cs, o->d_cl, o->d_cslot, o->cand_cap);
+  nms_rows_launch(ctx, G, nrows, 1);
   int* hn = (int*)ctx->h_pin;
   MVO_HIP(hipMemcpyAsync(hn, o->d_slot_tot, sizeof(int), hipMemcpyDeviceToHost, st));
   MVO_HIP(hipStreamSynchronize(st));
