@@ -91,7 +91,9 @@ int mvo_sync(mvo_ctx* ctx);
 void* mvo_stream(mvo_ctx* ctx);
 
 /* ---- a1: FeatureProcessor::detect_and_compute (src/feature_processor.cpp:19-23) ------------------
- * cv::ORB::detectAndCompute(img, noArray(), kps, desc).  img: mono8 (channels 1) or BGR8 (3).
+ * cv::ORB::detectAndCompute(img, noArray(), kps, desc).  `channels` names the sensor_msgs encoding of img everywhere
+ * in this header: 1 = mono8, 3 = bgr8, -3 = rgb8, 4 = bgra8, -4 = rgba8 (what cv_bridge::toCvShare(msg, BGR8) at
+ * src/mono_vo.cpp:94 accepts); colour is reduced with cvtColor(BGR2GRAY)'s 15-bit weights on the device.
  * Writes min(*n, cap) keypoints and 32-byte descriptors; *n is the full count (may exceed nfeatures
  * on score ties, as in OpenCV).  Key-point order is OpenCV's (KeyPointsFilter::retainBest order). */
 int mvo_orb_detect_and_compute(mvo_ctx* ctx, const uint8_t* img, int w, int h, int stride, int channels,

@@ -54,17 +54,22 @@ class Context:
         self._check(self._L.mvo_sync(self._h))
 
     @staticmethod
-    def _img(img):
+    def _img(img, encoding=None):
+        """-> (array, w, h, stride, channels code).  `encoding`: sensor_msgs name (mono8, bgr8, rgb8, bgra8, rgba8);
+        default mono8 for 2-D arrays and bgr8 / bgra8 for 3 / 4 channel arrays, like cv_bridge's BGR8 request."""
         img = np.ascontiguousarray(img, np.uint8)
         if img.ndim == 2:
             h, w = img.shape
             return img, w, h, w, 1
         h, w, c = img.shape
-        return img, w, h, w * c, c
+        code = {None: c, "bgr8": 3, "rgb8": -3, "bgra8": 4, "rgba8": -4, "mono8": 1}[encoding]
+        if abs(code) != c:
+            raise ValueError(f"encoding {encoding} does not match a {c}-channel image")
+        return img, w, h, w * c, code
 
     # -- a1 ------------------------------------------------------------------------------------------
-    def orb_detect_and_compute(self, img):
-        img, w, h, stride, ch = self._img(img)
+    def orb_detect_and_compute(self, img, encoding=None):
+        img, w, h, stride, ch = self._img(img, encoding)
         cap = int(self.cfg.max_points)
         kps = np.zeros(cap, KP_DTYPE)
         desc = np.zeros((cap, 32), np.uint8)

@@ -55,28 +55,32 @@ LkLevels lk_levels(int w, int h, int win, int max_level) {
   return L;
 }
 
-__global__ void bgr2gray_kernel(const u8* __restrict__ src, int spitch, u8* __restrict__ dst, int dpitch,
-                                int w, int h) {
+// colour -> gray as the reference's ingest does it: cv_bridge::toCvShare(msg, BGR8) (src/mono_vo.cpp:94; rgb8 is a
+// channel swap, bgra8 / rgba8 drop alpha) followed by OpenCV's cvtColor(BGR2GRAY) inside ORB: RGB2Gray<uchar> with the
+// 15-bit weights BY15 = 3735, GY15 = 19235, RY15 = 9798.  `bpp` 3 or 4, `rgb` = red comes first.
+__global__ void color2gray_kernel(const u8* __restrict__ src, int spitch, u8* __restrict__ dst, int dpitch, int w, int h, int bpp,
+                                  int rgb) {
   int x = blockIdx.x * blockDim.x + threadIdx.x;
   int y = blockIdx.y;
   if (x >= w) return;
-  const u8* p = src + (size_t)y * spitch + 3 * x;
-  // cvtColor(BGR2GRAY) 8-bit: RGB2Gray<uchar>, 15-bit weights BY15=3735 GY15=19235 RY15=9798.
-  dst[(size_t)y * dpitch + x] = (u8)((p[0] * 3735 + p[1] * 19235 + p[2] * 9798 + (1 << 14)) >> 15);
+  const u8* p = src + (size_t)y * spitch + bpp * x;
+  const int b = rgb ? p[2] : p[0], g = p[1], r = rgb ? p[0] : p[2];
+  dst[(size_t)y * dpitch + x] = (u8)((b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15);
 }
 
 int upload_gray(mvo_ctx* ctx, const uint8_t* img, int w, int h, int stride, int channels, u8* d_dst,
                 int dpitch, int slot) {
   if (channels == 1) {
     MVO_HIP(hipMemcpy2DAsync(d_dst, dpitch, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
-  } else if (channels == 3) {
+  } else if (channels == 3 || channels == -3 || channels == 4 || channels == -4) {
+    const int bpp = channels < 0 ? -channels : channels;
     u8* st = ctx->d_stage + (size_t)slot * ctx->stage_slot_bytes;
-    int spitch = align_up(w * 3, 64);
-    MVO_HIP(hipMemcpy2DAsync(st, spitch, img, stride, (size_t)w * 3, h, hipMemcpyHostToDevice, ctx->stream));
+    int spitch = align_up(w * bpp, 64);
+    MVO_HIP(hipMemcpy2DAsync(st, spitch, img, stride, (size_t)w * bpp, h, hipMemcpyHostToDevice, ctx->stream));
     dim3 grid((w + 255) / 256, h);
-    hipLaunchKernelGGL(bgr2gray_kernel, grid, dim3(256), 0, ctx->stream, st, spitch, d_dst, dpitch, w, h);
+    hipLaunchKernelGGL(color2gray_kernel, grid, dim3(256), 0, ctx->stream, st, spitch, d_dst, dpitch, w, h, bpp, channels < 0 ? 1 : 0);
   } else {
-    ctx->set_error("channels must be 1 (mono8) or 3 (BGR8)");
+    ctx->set_error("channels must be 1 (mono8), 3 (BGR8), -3 (RGB8), 4 (BGRA8) or -4 (RGBA8)");
     return MVO_E_ARG;
   }
   return MVO_OK;
@@ -117,7 +121,7 @@ extern "C" int mvo_create(const mvo_config* cfg, mvo_ctx** out) {
   MVO_HIP(hipMalloc(&ctx->d_status, np));
   MVO_HIP(hipMalloc(&ctx->d_err, np * sizeof(float)));
   MVO_HIP(hipMalloc(&ctx->d_npts, ctx->B * sizeof(int)));
-  ctx->stage_slot_bytes = (size_t)align_up(ctx->maxw * 3, 64) * ctx->maxh;
+  ctx->stage_slot_bytes = (size_t)align_up(ctx->maxw * 4, 64) * ctx->maxh;
   MVO_HIP(hipMalloc(&ctx->d_stage, ctx->stage_slot_bytes * ctx->B));
   ctx->h_pin_bytes = (size_t)16 << 20;
   MVO_HIP(hipHostMalloc(&ctx->h_pin, ctx->h_pin_bytes, hipHostMallocDefault));

@@ -136,6 +136,21 @@ def test_orb_bgr_input(ctx480, frames480):
     assert np.array_equal(gk["x"], ok["x"]) and np.array_equal(gd, od)
 
 
+def test_orb_ingest_encodings(ctx480, frames480):
+    """sensor_msgs encodings the node's cv_bridge call accepts: rgb8 / bgra8 / rgba8 reduce to the same gray image as
+    the bgr8 the oracle is given."""
+    rng = np.random.default_rng(9)
+    g = frames480[1]
+    bgr = np.clip(np.stack([g, g, g], -1).astype(np.int32) + rng.integers(-25, 25, g.shape + (3,)), 0, 255).astype(np.uint8)
+    ok, od = O.orb_detect_and_compute(bgr, 1000)
+    alpha = rng.integers(0, 256, g.shape + (1,), dtype=np.uint8)
+    variants = {"bgr8": bgr, "rgb8": np.ascontiguousarray(bgr[..., ::-1]), "bgra8": np.concatenate([bgr, alpha], -1),
+                "rgba8": np.concatenate([bgr[..., ::-1], alpha], -1)}
+    for enc, img in variants.items():
+        gk, gd = ctx480.orb_detect_and_compute(img, encoding=enc)
+        assert np.array_equal(gk["x"], ok["x"]) and np.array_equal(gk["y"], ok["y"]) and np.array_equal(gd, od), enc
+
+
 def test_matcher_bitexact(ctx480, frames480):
     _, d0 = O.orb_detect_and_compute(frames480[0], 1000)
     _, d1 = O.orb_detect_and_compute(frames480[1], 1000)
