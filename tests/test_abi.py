@@ -66,3 +66,18 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".inc", ".cpp")) or f == "Makefile":
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle_py" not in txt and "liborc" not in txt and "mvo_oracle.h" not in txt, f
+
+
+def test_header_is_plain_c_and_cxx(tmp_path):
+    """include/mvo.h is the FFI contract: it must compile as C11 and as C++17 on its own (no HIP, no torch, POD only),
+    and a C caller must be able to reference every declared entry point."""
+    import re
+    import subprocess
+    names = declared_symbols()
+    assert len(names) >= 25
+    body = "#include \"mvo.h\"\n#include <stddef.h>\nvoid* use_all(void) {\n  void* p = NULL;\n" + \
+           "".join(f"  p = (void*)&{n};\n" for n in names) + "  return p;\n}\n"
+    for name, cc, std in (("t.c", "gcc", "-std=c11"), ("t.cpp", "g++", "-std=c++17")):
+        src = tmp_path / name
+        src.write_text(body)
+        subprocess.check_call([cc, std, "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)])
