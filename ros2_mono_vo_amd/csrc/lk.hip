@@ -247,42 +247,85 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs A) {
     const int shI = lk_load_tile<LK_IT, LK_IT, LK_IP / 4>(S.it, I, lv.w, lv.h, lv.pitch, ipx - 1, ipy - 1, lane);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const u8* itb = (const u8*)S.it + shI;
     // ---- Scharr field on the 22x22 window-source positions (zero outside the image) --------------
-    for (int i = lane; i < LK_DT * LK_DT; i += 64) {
-      int ty = i / LK_DT, tx = i - ty * LK_DT;
-      int gx = ipx + tx, gy = ipy + ty;
-      short2 d = make_short2(0, 0);
-      if ((unsigned)gx < (unsigned)lv.w && (unsigned)gy < (unsigned)lv.h) {
-        const u8* c = itb + (ty + 1) * LK_IP + tx + 1;
-        int l0 = c[-LK_IP - 1], l1 = c[-1], l2 = c[LK_IP - 1];
-        int m0 = c[-LK_IP], m2 = c[LK_IP];
-        int r0 = c[-LK_IP + 1], r1 = c[1], r2 = c[LK_IP + 1];
-        int t0r = (r0 + r2) * 3 + r1 * 10, t0l = (l0 + l2) * 3 + l1 * 10;
-        int t1l = l2 - l0, t1m = m2 - m0, t1r = r2 - r0;
-        d.x = (short)(t0r - t0l);
-        d.y = (short)((t1r + t1l) * 3 + t1m * 10);
+    // Separable form, 11 pixels per lane (22 rows x 2 halves): with S = 3*(top + bottom) + 10*mid and D = bottom - top
+    // per column, dx = S[c+1] - S[c-1] and dy = 3*(D[c-1] + D[c+1]) + 10*D[c].  Three tile rows of 13 bytes come in as
+    // 4 aligned dwords each and are re-phased with v_alignbyte.
+    if (lane < 2 * LK_DT) {
+      const int ty = lane >> 1, hx = lane & 1, tx0 = 11 * hx;
+      const int bo = shI + tx0, ph = bo & 3;
+      const unsigned* rp = S.it + ty * (LK_IP / 4) + (bo >> 2);
+      unsigned col[3][4];   // bytes tx0 .. tx0+12 of tile rows ty, ty+1, ty+2 (byte 12 in col[.][3] bits 0-7)
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const unsigned d0 = rp[q * (LK_IP / 4)], d1 = rp[q * (LK_IP / 4) + 1], d2 = rp[q * (LK_IP / 4) + 2], d3 = rp[q * (LK_IP / 4) + 3];
+        col[q][0] = __builtin_amdgcn_alignbyte(d1, d0, ph);
+        col[q][1] = __builtin_amdgcn_alignbyte(d2, d1, ph);
+        col[q][2] = __builtin_amdgcn_alignbyte(d3, d2, ph);
+        col[q][3] = d3 >> (8 * ph);
       }
-      S.dt[i] = d;
+      int Sv[13], Dv[13];
+#pragma unroll
+      for (int c = 0; c < 13; c++) {
+        const int t = (int)((col[0][c >> 2] >> (8 * (c & 3))) & 0xFFu), m = (int)((col[1][c >> 2] >> (8 * (c & 3))) & 0xFFu),
+                  bt = (int)((col[2][c >> 2] >> (8 * (c & 3))) & 0xFFu);
+        Sv[c] = (t + bt) * 3 + m * 10;
+        Dv[c] = bt - t;
+      }
+      const int gy = ipy + ty;
+      const bool row_ok = (unsigned)gy < (unsigned)lv.h;
+      short2* dst = &S.dt[ty * LK_DT + tx0];
+#pragma unroll
+      for (int k = 0; k < 11; k++) {
+        const int gx = ipx + tx0 + k;
+        int dx = Sv[k + 2] - Sv[k];
+        int dy = (Dv[k] + Dv[k + 2]) * 3 + Dv[k + 1] * 10;
+        const bool ok = row_ok && (unsigned)gx < (unsigned)lv.w;
+        dst[k] = ok ? make_short2((short)dx, (short)dy) : make_short2(0, 0);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // ---- template in registers + exact A sums ---------------------------------------------------------
+    // Same machinery as the iteration: (p_k, p_k+1) 16-bit pairs by v_perm, the 4-tap fixed-point sums by two
+    // v_dot2c_i32_i16; the derivative field is interleaved (dx, dy), so its pairs come from two adjacent entries.
     int w00, w01, w10, w11;
     lk_weights(px - ipx, py - ipy, w00, w01, w10, w11);
     int Iv[7], Ixv[7], Iyv[7];
     int a11 = 0, a12 = 0, a22 = 0;
     if (active) {
-      const u8* i0 = itb + (r + 1) * LK_IP + x0 + 1;
-      const u8* i1 = i0 + LK_IP;
-      const short2* d0 = &S.dt[r * LK_DT + x0];
-      const short2* d1 = d0 + LK_DT;
+      const lk_short2 w0 = __builtin_bit_cast(lk_short2, (unsigned)w00 | ((unsigned)w01 << 16));
+      const lk_short2 w1 = __builtin_bit_cast(lk_short2, (unsigned)w10 | ((unsigned)w11 << 16));
+      {
+        const int bo = (r + 1) * LK_IP + x0 + 1 + shI, sh = bo & 3;
+        const unsigned* q = S.it + (bo >> 2);
+        const unsigned a0 = q[0], a1 = q[1], a2 = q[2];
+        const unsigned b0 = q[LK_IP / 4], b1 = q[LK_IP / 4 + 1], b2 = q[LK_IP / 4 + 2];
+        const unsigned r0lo = __builtin_amdgcn_alignbyte(a1, a0, sh), r0hi = __builtin_amdgcn_alignbyte(a2, a1, sh);
+        const unsigned r1lo = __builtin_amdgcn_alignbyte(b1, b0, sh), r1hi = __builtin_amdgcn_alignbyte(b2, b1, sh);
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+          const unsigned sel = (unsigned)i | (0x0Cu << 8) | ((unsigned)(i + 1) << 16) | (0x0Cu << 24);
+          const unsigned p0 = __builtin_amdgcn_perm(r0hi, r0lo, sel), p1 = __builtin_amdgcn_perm(r1hi, r1lo, sel);
+          int acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_short2, p0), w0, 0, false);
+          acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_short2, p1), w1, acc, false);
+          Iv[i] = descale(acc, 14 - 5);
+        }
+      }
+      const unsigned* d0 = (const unsigned*)&S.dt[r * LK_DT + x0];
+      const unsigned* d1 = d0 + LK_DT;
+      unsigned e0[8], e1[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) { e0[i] = d0[i]; e1[i] = d1[i]; }
 #pragma unroll
       for (int i = 0; i < 7; i++) {
-        Iv[i] = descale(__mul24(i0[i], w00) + __mul24(i0[i + 1], w01) + __mul24(i1[i], w10) + __mul24(i1[i + 1], w11), 14 - 5);
-        short2 e00 = d0[i], e01 = d0[i + 1], e10 = d1[i], e11 = d1[i + 1];
-        int ix = descale(__mul24(e00.x, w00) + __mul24(e01.x, w01) + __mul24(e10.x, w10) + __mul24(e11.x, w11), 14);
-        int iy = descale(__mul24(e00.y, w00) + __mul24(e01.y, w01) + __mul24(e10.y, w10) + __mul24(e11.y, w11), 14);
+        // (dx_i, dx_i+1) = low halves, (dy_i, dy_i+1) = high halves of two neighbouring (dx, dy) entries
+        const unsigned x0p = __builtin_amdgcn_perm(e0[i + 1], e0[i], 0x05040100u), y0p = __builtin_amdgcn_perm(e0[i + 1], e0[i], 0x07060302u);
+        const unsigned x1p = __builtin_amdgcn_perm(e1[i + 1], e1[i], 0x05040100u), y1p = __builtin_amdgcn_perm(e1[i + 1], e1[i], 0x07060302u);
+        int ix = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_short2, x0p), w0, 0, false);
+        ix = descale(__builtin_amdgcn_sdot2(__builtin_bit_cast(lk_short2, x1p), w1, ix, false), 14);
+        int iy = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_short2, y0p), w0, 0, false);
+        iy = descale(__builtin_amdgcn_sdot2(__builtin_bit_cast(lk_short2, y1p), w1, iy, false), 14);
         Ixv[i] = ix; Iyv[i] = iy;
         a11 += __mul24(ix, ix); a12 += __mul24(ix, iy); a22 += __mul24(iy, iy);
       }
