@@ -123,6 +123,14 @@ def test_orb_and_lk_bitexact_1080_c4():
         assert len(gk) == len(ok) and np.array_equal(gk["x"], ok["x"]) and np.array_equal(gk["y"], ok["y"]) and np.array_equal(gd, od)
 
 
+def test_orb_bitexact_wide_frame():
+    """Frames wider than 2048 px take the one-row-per-wavefront emit path (more than 32 segments per row)."""
+    from ros2_mono_vo_amd import Context
+    fr = synth.gen_stream(2304, 1296, 0x5EED0005, 1)
+    with Context(max_width=2304, max_height=1296, nfeatures=3000, max_points=8192) as ctx:
+        _check_orb(ctx, fr[0], 3000)
+
+
 def test_orb_bgr_input(ctx480, frames480):
     g = frames480[1]
     bgr = np.stack([g, g, g], -1)
