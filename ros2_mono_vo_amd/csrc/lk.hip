@@ -139,6 +139,28 @@ __device__ __forceinline__ long long wave_sum_exact(int v) {
   return (long long)wave_sum_i32_dpp(hi) * 65536LL + (long long)wave_sum_i32_dpp(lo);
 }
 
+// The same sum when every lane's partial is known to be small enough that the first PLAIN steps of the butterfly cannot
+// overflow: |v| < 2^28 lets groups of 8 lanes (3 steps) be summed in int32, |v| < 2^27 groups of 16 (4 steps); only
+// the remaining steps run on the hi / lo halves.  Bounds used by the callers: |J - I| <= 8160 and |Ix|, |Iy| <= 4080
+// (u8 image, 14-bit weights, 5 extra fractional bits; Scharr taps sum to 16), 7 pixels per lane.
+template <int PLAIN>
+__device__ __forceinline__ long long wave_sum_exact_bounded(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);  // row_half_mirror: groups of 8
+  if (PLAIN >= 4) v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);  // row_mirror: groups of 16
+  int lo = v & 0xFFFF, hi = v >> 16;
+  if (PLAIN < 4) {
+    lo += __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xF, 0xF, true);
+    hi += __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xF, 0xF, true);
+  }
+  lo += __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xA, 0xF, true);  // row_bcast:15
+  hi += __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xA, 0xF, true);
+  lo += __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xC, 0xF, true);  // row_bcast:31
+  hi += __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xC, 0xF, true);
+  return (long long)__builtin_amdgcn_readlane(hi, 63) * 65536LL + (long long)__builtin_amdgcn_readlane(lo, 63);
+}
+
 __device__ __forceinline__ void lk_weights(float a, float b, int& w00, int& w01, int& w10, int& w11) {
   const int W_BITS = 14;
   w00 = d_cv_round((1.f - a) * (1.f - b) * (1 << W_BITS));
@@ -333,7 +355,8 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs A) {
 #pragma unroll
       for (int i = 0; i < 7; i++) { Iv[i] = 0; Ixv[i] = 0; Iyv[i] = 0; }
     }
-    long long sA11 = wave_sum_exact(a11), sA12 = wave_sum_exact(a12), sA22 = wave_sum_exact(a22);
+    // per lane: 7 * 4080^2 < 2^27
+    long long sA11 = wave_sum_exact_bounded<4>(a11), sA12 = wave_sum_exact_bounded<4>(a12), sA22 = wave_sum_exact_bounded<4>(a22);
     float A11 = (float)(sA11 * A.cn) * FLT_SCALE;
     float A12 = (float)(sA12 * A.cn) * FLT_SCALE;
     float A22 = (float)(sA22 * A.cn) * FLT_SCALE;
@@ -369,7 +392,7 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs A) {
       int s1, s2;
       lk_accumulate<false>(S.jt, (r + ddy) * LK_JP + x0 + ddx + shJ, active, (unsigned)w00 | ((unsigned)w01 << 16),
                            (unsigned)w10 | ((unsigned)w11 << 16), Iv, Ixv, Iyv, s1, s2);
-      long long sb1 = wave_sum_exact(s1), sb2 = wave_sum_exact(s2);
+      long long sb1 = wave_sum_exact_bounded<3>(s1), sb2 = wave_sum_exact_bounded<3>(s2);  // per lane: 7 * 8160 * 4080 < 2^28
       float b1 = (float)(sb1 * A.cn) * FLT_SCALE;
       float b2 = (float)(sb2 * A.cn) * FLT_SCALE;
       float dx = (A12 * b2 - A22 * b1) * D;
@@ -403,7 +426,7 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs A) {
         int s1, s2;
         lk_accumulate<true>(S.jt, (r + ddy) * LK_JP + x0 + ddx + shJ, active, (unsigned)w00 | ((unsigned)w01 << 16),
                             (unsigned)w10 | ((unsigned)w11 << 16), Iv, Ixv, Iyv, s1, s2);
-        long long se = wave_sum_exact(s1);
+        long long se = (long long)wave_sum_i32_dpp(s1);  // 64 * 7 * 8160 fits 32 bits
         float errval = (float)(se * A.cn);
         errv = errval * 1.f / (float)(32 * LK_WIN * A.cn * LK_WIN);
       }
