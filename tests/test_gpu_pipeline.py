@@ -92,3 +92,31 @@ def test_batch_with_empty_and_lost_streams():
                 assert l.n_tracked == o.n_tracked
             else:
                 assert l.n_tracked < 0.5 * max(l.n_prev, 1) or l.n_pnp_inliers < 0.5 * max(l.n_tracked, 1)
+
+
+def test_two_slot_ring_matches_preloaded_ring():
+    """Live-stream use: a 2-slot ring filled just before each step gives the same results as a ring
+    that holds the whole sequence."""
+    W, H, NF, STEPS, B = 640, 480, 1000, 3, 2
+    K = synth.default_K(W, H)
+    streams = [synth.gen_stream(W, H, 0x5EED0400 + s, STEPS + 1) for s in range(B)]
+
+    def run(ring):
+        outs = []
+        with Context(max_width=W, max_height=H, batch=B, nfeatures=NF, max_points=4096, ring_frames=ring) as ctx:
+            ctx.batch_set_intrinsics(K)
+            for s in range(B):
+                ctx.batch_preload_frame(s, 0, streams[s][0])
+            ctx.batch_seed(0)
+            for s in range(B):
+                ctx.batch_set_landmarks(s, planar_landmarks(K)(ctx.batch_get_tracks(s)))
+            for k in range(1, STEPS + 1):
+                slot = k % ring
+                for s in range(B):
+                    ctx.batch_preload_frame(s, slot, streams[s][k])
+                out = ctx.batch_step(slot, _lib.STAGE_ALL)
+                outs.append([(o.n_tracked, o.n_keypoints, o.n_matches, o.n_pnp_inliers, o.score_h, o.score_f, o.n_triangulated,
+                              tuple(o.rvec), tuple(o.tvec)) for o in out])
+        return outs
+
+    assert run(2) == run(STEPS + 1)
