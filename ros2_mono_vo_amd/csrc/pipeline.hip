@@ -538,6 +538,9 @@ extern "C" int mvo_batch_step(mvo_ctx* ctx, int frame_idx, unsigned stages, mvo_
   if (do_hf) {
     // Tracker::has_parallax: key-frame positions of the tracked landmarks vs their current positions
     MVO_HIP(hipStreamWaitEvent(p->s_hf, p->ev_lk, 0));
+    // H / F are only read at the end of the step: let them start after ORB's detect kernels, so that FAST shares its
+    // SIMDs with the PnP chain alone
+    if (do_orb) MVO_HIP(hipStreamWaitEvent(p->s_hf, ctx->orb->ev_counts, 0));
     { ProfScope ps(ctx, "ransac_h", p->s_hf);
       geom_ransac_h(ctx, B, p->d_cur_kf, p->d_cur_pts, p->d_ncur, ctx->cfg.ransac_reproj_thresh, 2000, 0.995, g->d_mask2, g->d_model2,
                     g->d_result2, p->s_hf); }
