@@ -274,9 +274,9 @@ __device__ inline void gl_jacobi_svd12_lds(gl_lds_double* At, gl_lds_double* W, 
   for (int iter = 0; iter < 30; iter++) {
     bool changed = false;
     for (int i = 0; i < 11; i++) {
-      double Ai[12];
+      double Ai[12], Vi[12];
 #pragma unroll
-      for (int k = 0; k < 12; k++) Ai[k] = At[i * 12 + k];
+      for (int k = 0; k < 12; k++) { Ai[k] = At[i * 12 + k]; Vi[k] = Vt[i * 12 + k]; }
       double a = W[i];
       bool touched = false;
       for (int j = i + 1; j < 12; j++) {
@@ -307,17 +307,17 @@ __device__ inline void gl_jacobi_svd12_lds(gl_lds_double* At, gl_lds_double* W, 
         }
         W[j] = b;
         touched = true;
-#pragma unroll 4
-        for (int k = 0; k < 12; k++) {   // V rows stay in LDS: caching row i as well cost 24 more VGPRs
-          double vi = Vt[i * 12 + k], vj = Vt[j * 12 + k];
-          double t0 = c * vi + s * vj;
-          double t1 = -s * vi + c * vj;
-          Vt[i * 12 + k] = t0; Vt[j * 12 + k] = t1;
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+          double vj = Vt[j * 12 + k];
+          double t0 = c * Vi[k] + s * vj;
+          double t1 = -s * Vi[k] + c * vj;
+          Vi[k] = t0; Vt[j * 12 + k] = t1;
         }
       }
       if (touched) {
 #pragma unroll
-        for (int k = 0; k < 12; k++) At[i * 12 + k] = Ai[k];
+        for (int k = 0; k < 12; k++) { At[i * 12 + k] = Ai[k]; Vt[i * 12 + k] = Vi[k]; }
         W[i] = a;
         changed = true;
       }

@@ -452,35 +452,28 @@ __device__ GL_NOINLINE void ep_gauss_newton(const double* L, const double* rho, 
 
 __device__ GL_NOINLINE double ep_compute_R_and_t(EpnpState& e, const double* ut, const double* betas, double R[3][3], double t[3]) {
   const int n = EP_N;
-#pragma unroll 1
   for (int i = 0; i < 4; i++) e.ccs[i][0] = e.ccs[i][1] = e.ccs[i][2] = 0.0f;
-#pragma unroll 1
   for (int i = 0; i < 4; i++) {
     const double* v = ut + 12 * (11 - i);
     for (int j = 0; j < 4; j++)
       for (int k = 0; k < 3; k++) e.ccs[j][k] += betas[i] * v[3 * j + k];
   }
-#pragma unroll 1
   for (int i = 0; i < n; i++) {
     double* a = &e.alphas[4 * i];
     double* pc = &e.pcs[3 * i];
     for (int j = 0; j < 3; j++) pc[j] = a[0] * e.ccs[0][j] + a[1] * e.ccs[1][j] + a[2] * e.ccs[2][j] + a[3] * e.ccs[3][j];
   }
   if (e.pcs[2] < 0.0) {
-#pragma unroll 1
     for (int i = 0; i < 4; i++)
       for (int j = 0; j < 3; j++) e.ccs[i][j] = -e.ccs[i][j];
-#pragma unroll 1
     for (int i = 0; i < n; i++) { e.pcs[3 * i] = -e.pcs[3 * i]; e.pcs[3 * i + 1] = -e.pcs[3 * i + 1]; e.pcs[3 * i + 2] = -e.pcs[3 * i + 2]; }
   }
   // estimate_R_and_t
   double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0};
-#pragma unroll 1
   for (int i = 0; i < n; i++)
     for (int j = 0; j < 3; j++) { pc0[j] += e.pcs[3 * i + j]; pw0[j] += e.pws[3 * i + j]; }
   for (int j = 0; j < 3; j++) { pc0[j] /= n; pw0[j] /= n; }
   double abt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, abt_d[3], abt_u[9], abt_vt[9], abt_v[9];
-#pragma unroll 1
   for (int i = 0; i < n; i++) {
     double* pc = &e.pcs[3 * i];
     double* pw = &e.pws[3 * i];
@@ -503,7 +496,6 @@ __device__ GL_NOINLINE double ep_compute_R_and_t(EpnpState& e, const double* ut,
   t[2] = pc0[2] - ep_dot(R[2], pw0);
   // reprojection_error
   double sum2 = 0.0;
-#pragma unroll 1
   for (int i = 0; i < n; i++) {
     double* pw = &e.pws[3 * i];
     double Xc = ep_dot(R[0], pw) + t[0];
@@ -524,7 +516,6 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
   const int n = EP_N;
   EpnpState e;
   e.fu = cam.fx; e.fv = cam.fy; e.uc = cam.cx; e.vc = cam.cy;
-#pragma unroll 1
   for (int i = 0; i < n; i++) {
     e.pws[3 * i] = obj[3 * i]; e.pws[3 * i + 1] = obj[3 * i + 1]; e.pws[3 * i + 2] = obj[3 * i + 2];
     double xu, yu;
@@ -535,20 +526,17 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
   }
   // choose_control_points
   e.cws[0][0] = e.cws[0][1] = e.cws[0][2] = 0;
-#pragma unroll 1
   for (int i = 0; i < n; i++)
     for (int j = 0; j < 3; j++) e.cws[0][j] += e.pws[3 * i + j];
   for (int j = 0; j < 3; j++) e.cws[0][j] /= n;
   {
     double pw0[3 * EP_N];
-#pragma unroll 1
     for (int i = 0; i < n; i++)
       for (int j = 0; j < 3; j++) pw0[3 * i + j] = e.pws[3 * i + j] - e.cws[0][j];
     double pw0tpw0[9], dc[3], U[9];
     for (int a = 0; a < 3; a++)
       for (int b = a; b < 3; b++) {
         double s = 0;
-#pragma unroll 1
         for (int i = 0; i < n; i++) s += pw0[3 * i + a] * pw0[3 * i + b];
         pw0tpw0[a * 3 + b] = pw0tpw0[b * 3 + a] = s;
       }
@@ -564,7 +552,6 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
     for (int i = 0; i < 3; i++)
       for (int j = 1; j < 4; j++) cc[3 * i + j - 1] = e.cws[j][i] - e.cws[0][i];
     gl_invert3_svd(cc, ci);
-#pragma unroll 1
     for (int i = 0; i < n; i++) {
       double* pi = &e.pws[3 * i];
       double* a = &e.alphas[4 * i];
@@ -578,7 +565,6 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
   double* ws2 = ws + 144;
   {
     double* M = ws2;
-#pragma unroll 1
     for (int i = 0; i < n; i++) {
       const double* as = &e.alphas[4 * i];
       double u = e.us[2 * i], v = e.us[2 * i + 1];
@@ -591,20 +577,15 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
     }
     double* mtm = ws;
     double d[12];
-#pragma unroll 1
     for (int a = 0; a < 12; a++)
-#pragma unroll 1
       for (int b = a; b < 12; b++) {
         double s = 0;
-#pragma unroll
-        for (int i = 0; i < 2 * EP_N; i++) s += M[i * 12 + a] * M[i * 12 + b];
+        for (int i = 0; i < 2 * n; i++) s += M[i * 12 + a] * M[i * 12 + b];
         mtm[a * 12 + b] = mtm[b * 12 + a] = s;
       }
     double* tv = ws2;  // M is dead from here on
     // Ut rows = left singular vectors = rows of the rotated A^T: run the one-sided Jacobi directly on mtm^T
-#pragma unroll 1
     for (int i = 0; i < 12; i++)
-#pragma unroll 1
       for (int j = i + 1; j < 12; j++) { double t = mtm[i * 12 + j]; mtm[i * 12 + j] = mtm[j * 12 + i]; mtm[j * 12 + i] = t; }
     // ut == mtm.  Lanes whose workspace is in LDS take the unrolled 12 x 12 routine; the private-memory lanes of a wide
     // RANSAC round take the general one (same arithmetic)
@@ -653,7 +634,6 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
   double Rs[4][3][3], ts[4][3];
   {  // find_betas_approx_1
     double l[24], b4[4];
-#pragma unroll 1
     for (int i = 0; i < 6; i++) { l[i * 4] = l_6x10[i * 10]; l[i * 4 + 1] = l_6x10[i * 10 + 1]; l[i * 4 + 2] = l_6x10[i * 10 + 3]; l[i * 4 + 3] = l_6x10[i * 10 + 6]; }
     gl_solve_svd_ws(l, 6, 4, rho, b4, ws2, ws2 + 36);
     double* betas = Betas[1];
@@ -664,7 +644,6 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
   rep_errors[1] = ep_compute_R_and_t(e, ut, Betas[1], Rs[1], ts[1]);
   {  // find_betas_approx_2
     double l[18], b3[3];
-#pragma unroll 1
     for (int i = 0; i < 6; i++) { l[i * 3] = l_6x10[i * 10]; l[i * 3 + 1] = l_6x10[i * 10 + 1]; l[i * 3 + 2] = l_6x10[i * 10 + 2]; }
     gl_solve_svd_ws(l, 6, 3, rho, b3, ws2, ws2 + 36);
     double* betas = Betas[2];
@@ -677,7 +656,6 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
   rep_errors[2] = ep_compute_R_and_t(e, ut, Betas[2], Rs[2], ts[2]);
   {  // find_betas_approx_3
     double l[30], b5[5];
-#pragma unroll 1
     for (int i = 0; i < 6; i++)
       for (int j = 0; j < 5; j++) l[i * 5 + j] = l_6x10[i * 10 + j];
     gl_solve_svd_ws(l, 6, 5, rho, b5, ws2, ws2 + 36);
@@ -721,9 +699,7 @@ struct PnPModel {
       gm_rodrigues_v2m(rvec, R, nullptr);
       cam = P.cam;
     }
-    // not inlined: inlined into the scoring loops the compiler software-pipelines several projections (two f64
-    // divisions in flight) and the kernel body goes from ~150 to 232 VGPRs
-    __device__ GL_NOINLINE float err(const float* M3, const float* m2) const {
+    __device__ __forceinline__ float err(const float* M3, const float* m2) const {
       double M[3] = {M3[0], M3[1], M3[2]}, m[2];
       gm_project_point(R, nullptr, t, cam, M, m, nullptr, nullptr);
       float px = (float)m[0], py = (float)m[1];
