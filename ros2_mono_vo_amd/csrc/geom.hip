@@ -588,7 +588,7 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
       for (int a = 0; a < 12; a++)
         for (int b = a; b < 12; b++) { L[a * 12 + b] = LL[q]; L[b * 12 + a] = LL[q]; q++; }
       // cvSVD(&_LL, &_LW, 0, &_LV, MODIFY_A + V_T): Vt; run the one-sided Jacobi on L^T (= L)
-      gl_jacobi_svd12_lds((gl_lds_double*)L, (gl_lds_double*)LW, (gl_lds_double*)LV);
+      gl_jacobi_svd12_lds<true>((gl_lds_double*)L, (gl_lds_double*)LW, (gl_lds_double*)LV);
       double* RRt = LV + 11 * 12;
       double RR[9], ttv[3];
       for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) RR[r * 3 + c] = RRt[r * 4 + c]; ttv[r] = RRt[r * 4 + 3]; }

@@ -127,7 +127,9 @@ __device__ GL_NOINLINE void gl_jacobi_eigen(double* A, int n, double* W, double*
 
 // Second half of JacobiSVDImpl_: singular values, descending sort (rows of At / Vt follow), unit left vectors, and the
 // seeded Gram-Schmidt completion for vanishing singular values.  W: squared row norms are NOT needed, it is recomputed.
-__device__ GL_NOINLINE void gl_jacobi_svd_tail(double* At, int astep, double* W, double* Wout, double* Vt, int m, int n, int n1) {
+// want_u with Vt == nullptr: the caller only reads the left vectors (EPnP's cvSVD(MtM, D, Ut, 0)).  The reference
+// still carries V along there, but no value of At or W ever depends on V, so leaving it out changes no result.
+__device__ GL_NOINLINE void gl_jacobi_svd_tail(double* At, int astep, double* W, double* Wout, double* Vt, int m, int n, int n1, bool want_u) {
   const double minval = DBL_MIN, eps = DBL_EPSILON * 10;
   int i, j, k, iter;
   double s, sd;
@@ -144,14 +146,14 @@ __device__ GL_NOINLINE void gl_jacobi_svd_tail(double* At, int astep, double* W,
       if (W[j] < W[k]) j = k;
     if (i != j) {
       gl_swap(W[i], W[j]);
-      if (Vt) {
+      if (want_u)
         for (k = 0; k < m; k++) gl_swap(At[i * astep + k], At[j * astep + k]);
+      if (Vt)
         for (k = 0; k < n; k++) gl_swap(Vt[i * n + k], Vt[j * n + k]);
-      }
     }
   }
   for (i = 0; i < n; i++) Wout[i] = W[i];
-  if (!Vt) return;
+  if (!want_u) return;
   GlRng rng(0x12345678);
   for (i = 0; i < n1; i++) {
     sd = i < n ? W[i] : 0;
@@ -189,7 +191,7 @@ __device__ GL_NOINLINE void gl_jacobi_svd_tail(double* At, int astep, double* W,
 
 // JacobiSVDImpl_<double>: At has n rows of length m (stride astep); rows 0..n1-1 become left singular
 // vectors (the rows beyond n are the seeded Gram-Schmidt completion); Vt n x n.
-__device__ GL_NOINLINE void gl_jacobi_svd(double* At, int astep, double* Wout, double* Vt, int m, int n, int n1) {
+__device__ GL_NOINLINE void gl_jacobi_svd(double* At, int astep, double* Wout, double* Vt, int m, int n, int n1, bool want_u) {
   const double eps = DBL_EPSILON * 10;
   double W[GL_MAXN];
   int i, j, k, iter, max_iter = m > 30 ? m : 30;
@@ -243,7 +245,7 @@ __device__ GL_NOINLINE void gl_jacobi_svd(double* At, int astep, double* Wout, d
       }
     if (!changed) break;
   }
-  gl_jacobi_svd_tail(At, astep, W, Wout, Vt, m, n, n1);
+  gl_jacobi_svd_tail(At, astep, W, Wout, Vt, m, n, n1, want_u);
 }
 
 // The 12 x 12 case of JacobiSVDImpl_ (EPnP's M^T M, the DLT of cvFindExtrinsicCameraParams2) with the matrices in LDS:
@@ -260,6 +262,8 @@ __device__ __forceinline__ bool gl_is_lds(const void* p) {
   return false;
 #endif
 }
+// WITH_V false: left vectors only (Vt unused), see gl_jacobi_svd_tail.
+template <bool WITH_V>
 __device__ inline void gl_jacobi_svd12_lds(gl_lds_double* At, gl_lds_double* W, gl_lds_double* Vt) {
   const double eps = DBL_EPSILON * 10;
   for (int i = 0; i < 12; i++) {
@@ -267,16 +271,18 @@ __device__ inline void gl_jacobi_svd12_lds(gl_lds_double* At, gl_lds_double* W, 
 #pragma unroll
     for (int k = 0; k < 12; k++) { double t = At[i * 12 + k]; sd += t * t; }
     W[i] = sd;
+    if (WITH_V) {
 #pragma unroll
-    for (int k = 0; k < 12; k++) Vt[i * 12 + k] = 0;
-    Vt[i * 12 + i] = 1;
+      for (int k = 0; k < 12; k++) Vt[i * 12 + k] = 0;
+      Vt[i * 12 + i] = 1;
+    }
   }
   for (int iter = 0; iter < 30; iter++) {
     bool changed = false;
     for (int i = 0; i < 11; i++) {
       double Ai[12], Vi[12];
 #pragma unroll
-      for (int k = 0; k < 12; k++) { Ai[k] = At[i * 12 + k]; Vi[k] = Vt[i * 12 + k]; }
+      for (int k = 0; k < 12; k++) { Ai[k] = At[i * 12 + k]; Vi[k] = WITH_V ? Vt[i * 12 + k] : 0.0; }
       double a = W[i];
       bool touched = false;
       for (int j = i + 1; j < 12; j++) {
@@ -307,24 +313,26 @@ __device__ inline void gl_jacobi_svd12_lds(gl_lds_double* At, gl_lds_double* W, 
         }
         W[j] = b;
         touched = true;
+        if (WITH_V) {
 #pragma unroll
-        for (int k = 0; k < 12; k++) {
-          double vj = Vt[j * 12 + k];
-          double t0 = c * Vi[k] + s * vj;
-          double t1 = -s * Vi[k] + c * vj;
-          Vi[k] = t0; Vt[j * 12 + k] = t1;
+          for (int k = 0; k < 12; k++) {
+            double vj = Vt[j * 12 + k];
+            double t0 = c * Vi[k] + s * vj;
+            double t1 = -s * Vi[k] + c * vj;
+            Vi[k] = t0; Vt[j * 12 + k] = t1;
+          }
         }
       }
       if (touched) {
 #pragma unroll
-        for (int k = 0; k < 12; k++) { At[i * 12 + k] = Ai[k]; Vt[i * 12 + k] = Vi[k]; }
+        for (int k = 0; k < 12; k++) { At[i * 12 + k] = Ai[k]; if (WITH_V) Vt[i * 12 + k] = Vi[k]; }
         W[i] = a;
         changed = true;
       }
     }
     if (!changed) break;
   }
-  gl_jacobi_svd_tail((double*)At, 12, (double*)W, (double*)W, (double*)Vt, 12, 12, 12);
+  gl_jacobi_svd_tail((double*)At, 12, (double*)W, (double*)W, WITH_V ? (double*)Vt : nullptr, 12, 12, 12, true);
 }
 
 // JacobiSVDImpl_<double> for compile-time sizes, everything in registers: the same operation sequence as
@@ -437,7 +445,7 @@ __device__ GL_NOINLINE void gl_svd_compute(const double* A, int m, int n, double
     for (int i = 0; i < m; i++)
       for (int j = 0; j < n; j++) ta[i * mm + j] = A[i * n + j];
   }
-  gl_jacobi_svd(ta, mm, w, tv, mm, nn, urows);
+  gl_jacobi_svd(ta, mm, w, tv, mm, nn, urows, tv != nullptr);
   if (!at) {
     if (U)
       for (int i = 0; i < urows; i++)
@@ -535,7 +543,7 @@ __device__ inline void gl_solve_svd_ws(const double* A, int m, int n, const doub
   double w[6], buf[1];
   for (int i = 0; i < m; i++)
     for (int j = 0; j < n; j++) at[j * m + i] = A[i * n + j];
-  gl_jacobi_svd(at, m, w, vt, m, n, n);
+  gl_jacobi_svd(at, m, w, vt, m, n, n, true);
   gl_svbksb(m, n, w, at, m, vt, n, b, 1, 1, x, 1, buf);
 }
 
@@ -544,7 +552,7 @@ __device__ inline void gl_solve_svd(const double* A, int m, int n, const double*
   double at[36], w[6], vt[36], buf[1];
   for (int i = 0; i < m; i++)
     for (int j = 0; j < n; j++) at[j * m + i] = A[i * n + j];
-  gl_jacobi_svd(at, m, w, vt, m, n, n);
+  gl_jacobi_svd(at, m, w, vt, m, n, n, true);
   gl_svbksb(m, n, w, at, m, vt, n, b, 1, 1, x, 1, buf);
 }
 
@@ -553,7 +561,7 @@ __device__ GL_NOINLINE void gl_invert3_svd_general(const double* A, double* Ainv
   double at[9], w[3], vt[9], buf[3];
   for (int i = 0; i < 3; i++)
     for (int j = 0; j < 3; j++) at[j * 3 + i] = A[i * 3 + j];
-  gl_jacobi_svd(at, 3, w, vt, 3, 3, 3);
+  gl_jacobi_svd(at, 3, w, vt, 3, 3, 3, true);
   gl_svbksb(3, 3, w, at, 3, vt, 3, nullptr, 0, 3, Ainv, 3, buf);
 }
 __device__ inline void gl_invert3_svd(const double* A, double* Ainv) {

@@ -583,14 +583,13 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
         for (int i = 0; i < 2 * n; i++) s += M[i * 12 + a] * M[i * 12 + b];
         mtm[a * 12 + b] = mtm[b * 12 + a] = s;
       }
-    double* tv = ws2;  // M is dead from here on
-    // Ut rows = left singular vectors = rows of the rotated A^T: run the one-sided Jacobi directly on mtm^T
-    for (int i = 0; i < 12; i++)
-      for (int j = i + 1; j < 12; j++) { double t = mtm[i * 12 + j]; mtm[i * 12 + j] = mtm[j * 12 + i]; mtm[j * 12 + i] = t; }
+    // Ut rows = left singular vectors = rows of the rotated A^T: the one-sided Jacobi runs directly on mtm^T, and mtm
+    // is bit-for-bit symmetric (both halves are stored from the same sum), so no transposition is needed
     // ut == mtm.  Lanes whose workspace is in LDS take the unrolled 12 x 12 routine; the private-memory lanes of a wide
     // RANSAC round take the general one (same arithmetic)
-    if (gl_is_lds(ws)) gl_jacobi_svd12_lds((gl_lds_double*)mtm, (gl_lds_double*)(ws + 288), (gl_lds_double*)tv);
-    else gl_jacobi_svd(mtm, 12, d, tv, 12, 12, 12);
+    // cvSVD(MtM, D, Ut, 0): only the left vectors are read, V is not formed (no value of Ut depends on it)
+    if (gl_is_lds(ws)) gl_jacobi_svd12_lds<false>((gl_lds_double*)mtm, (gl_lds_double*)(ws + 288), nullptr);
+    else gl_jacobi_svd(mtm, 12, d, nullptr, 12, 12, 12, true);
   }
   // dv (4 x 6 x 3) and L_6x10 live in the workspace (the V block is free after the SVD) and their loops stay rolled:
   // as register arrays they pushed this function to ~250 VGPRs
