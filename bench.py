@@ -59,6 +59,10 @@ def cpu_baseline(seed, w, h, K, nfeatures, n_frames):
     return done / dt, done
 
 
+STAGE_TIMERS = ("frame_fanout", "lk_pyramid", "lk_track", "lk_filter", "orb_detect", "orb_select", "orb_blur", "orb_describe", "match",
+                "pnp", "ransac_h", "ransac_f", "triangulate")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -71,6 +75,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic streams generated per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=50, help="consecutive oracle steps timed for cpu_baseline (~0.2 s each)")
+    ap.add_argument("--per-step", action="store_true", help="diagnostic: add the stage timers of every step (step_stage_ms)")
     ap.add_argument("--stages", type=lambda v: int(v, 0), default=None,
                     help="diagnostic: MVO_STAGE_* mask to run instead of the full step (the line then lists stages_missing)")
     args = ap.parse_args()
@@ -125,12 +130,16 @@ def main():
     t0 = time.perf_counter()
     lk_points = 0
     last = None
-    step_ms = []
+    step_ms, step_stage, prev_cum = [], [], {}
     for k in range(K):
         ts = time.perf_counter()
         last = ctx.batch_step(1 + Wm + k, stages)   # synchronous: returns when the step's results are on the host
         step_ms.append(round((time.perf_counter() - ts) * 1e3, 3))
         lk_points += sum(r.n_prev for r in last)
+        if args.per_step:
+            cum = {n: ctx.profile_read(n)[0] for n in STAGE_TIMERS}
+            step_stage.append({n: round(cum[n] - prev_cum.get(n, 0.0), 3) for n in STAGE_TIMERS})
+            prev_cum = cum
     ctx.sync()
     torch.cuda.synchronize()
     if dist is not None:
@@ -140,8 +149,7 @@ def main():
     dt = parallel.max_over_ranks(dt, dist, device="cuda")
 
     prof = {}
-    for name in ("frame_fanout", "lk_pyramid", "lk_track", "lk_filter", "orb_detect", "orb_select", "orb_blur", "orb_describe", "match", "pnp",
-                 "ransac_h", "ransac_f", "triangulate"):
+    for name in STAGE_TIMERS:
         ms, n = ctx.profile_read(name)
         if n:
             prof[name] = {"ms_total": round(ms, 4), "launches": n, "ms_avg": round(ms / n, 5)}
@@ -190,6 +198,8 @@ def main():
             "stage_ms": prof,
             "step_ms": step_ms,
         }
+        if step_stage:
+            line["step_stage_ms"] = step_stage
         if not args.no_cpu_baseline:
             fps, nfr = cpu_baseline(0x5EED0003 + 1, W, H, Kmat, args.nfeatures, args.cpu_frames)
             line["cpu_baseline"] = {"value": round(fps, 3), "unit": "frames/s", "cores": 1, "kind": "port",

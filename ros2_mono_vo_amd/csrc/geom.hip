@@ -60,7 +60,7 @@ __global__ __launch_bounds__(RS_T, RS_WAVES_PER_EU) void ransac_kernel(RansacArg
   // matrices live in LDS; when more than that many iterations are still owed, the round is 64 wide and lanes >= CH0 keep
   // their matrices in private memory (slower per solve, four times the hypotheses per round) - the tail of a hard
   // problem otherwise gates the whole batch launch.
-  constexpr int CH0 = M::CH, RS_CH = 64;
+  constexpr int CH0 = M::CH, RS_CH = M::WIDE ? 64 : M::CH;
   // per-lane workspace stride: == 1 (mod 32) doubles, so lane-uniform 8-byte accesses of 16 lanes fall into distinct banks
   constexpr int WSS = M::WS > 0 ? ((M::WS + 30) / 32) * 32 + 1 : 1;
   __shared__ double s_ws[(M::WS > 0 ? CH0 : 1) * WSS];
@@ -204,8 +204,8 @@ __global__ __launch_bounds__(RS_T, RS_WAVES_PER_EU) void ransac_kernel(RansacArg
         for (int k = 0; k < M::PT2; k++) ms2[i * M::PT2 + k] = m2[(size_t)id * M::PT2 + k];
       }
       double models[M::MAXM * M::MS];
-      double priv[M::WS > 0 ? M::WS : 1];  // lanes >= CH0 of a wide round
-      nm = M::solve(A.P, ms1, ms2, models, M::WS > 0 ? (tid < CH0 ? s_ws + tid * WSS : priv) : s_ws);
+      double priv[M::WS > 0 && M::WIDE ? M::WS : 1];  // lanes >= CH0 of a wide round
+      nm = M::solve(A.P, ms1, ms2, models, M::WS > 0 ? (!M::WIDE || tid < CH0 ? s_ws + tid * WSS : priv) : s_ws);
       if (nm < 0) nm = 0;
       if (nm > M::MAXM) nm = M::MAXM;
       s_nmodels[tid] = nm;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(RS_T, RS_WAVES_PER_EU) void ransac_kernel(RansacArg
             s_cnt[hyp][q] = __float_as_int(e[count / 2]);
           }
         }
-      } else if (hyp < nsolve) {
+      } else if (hyp < nsolve && part < parts) {   // lanes past parts * ch (ch not a divisor of 64) sit the scoring out
         const int nmh = s_nmodels[hyp];
         for (int q = 0; q < nmh; q++) {
           typename M::Scorer sc;
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(RS_T, RS_WAVES_PER_EU) void ransac_kernel(RansacArg
   if (tid == 0) { result[0] = maxGood > 0; result[1] = maxGood; result[2] = s_ctl[3]; result[3] = s_ctl[4]; result[4] = s_ctl[7]; }
 #ifdef RS_TIMING
   RS_TICK(5)
-  if (tid == 0 && (slot == 0 || slot == 100))
+  if (tid == 0 && slot < 4)
     printf("RS_TIMING MP=%d slot=%d n=%d iters=%d scored=%d | draw %lld check %lld solve %lld score %lld replay %lld mask %lld (100MHz ticks)\n", M::MP, slot, count,
            s_ctl[3], s_ctl[7], tm[0], tm[1], tm[2], tm[3], tm[4], tm[5]);
 #endif

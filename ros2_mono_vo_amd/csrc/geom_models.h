@@ -30,6 +30,7 @@ struct ModelParams { CamK cam; };
 struct HModel {
   static constexpr int MP = 4, MAXM = 1, MS = 9, PT1 = 2, PT2 = 2;
   static constexpr int CH = 16, WS = 81 + 9 + 81;  // LtL, W, V
+  static constexpr bool WIDE = true;
   static constexpr int LMEDS_BELOW = 0;
 
   __device__ static bool check_subset(const float* ms1, const float* ms2) {
@@ -113,6 +114,7 @@ struct HModel {
 struct FModel {
   static constexpr int MP = 7, MAXM = 3, MS = 9, PT1 = 2, PT2 = 2;
   static constexpr int CH = 16, WS = 63 + 81 + 81 + 49;  // a, v, ta, tv
+  static constexpr bool WIDE = true;
   static constexpr int LMEDS_BELOW = 15;  // findFundamentalMat: FM_RANSAC with fewer than 15 points runs LMedS (fundam.cpp)
 
   __device__ static bool check_subset(const float* ms1, const float* ms2) {
@@ -680,7 +682,11 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
 
 struct PnPModel {
   static constexpr int MP = 5, MAXM = 1, MS = 6, PT1 = 3, PT2 = 2;
-  static constexpr int CH = 16, WS = 144 + 144 + 12;  // MtM -> Ut; M / V / the small solves' workspaces; singular values
+  // 24 hypotheses per round, every round in LDS (24 x 321 doubles = 61.6 KB): a round is latency bound, ~0.85 ms
+  // whatever its width up to the LDS capacity, while a 64-wide round with 40 workspaces in private memory took 3.8 ms -
+  // more per hypothesis than the LDS rounds, and coarser when the iteration bound shrinks mid-way
+  static constexpr int CH = 24, WS = 144 + 144 + 12;  // MtM -> Ut; M / the small solves' workspaces; singular values
+  static constexpr bool WIDE = false;
   static constexpr int LMEDS_BELOW = 0;
   __device__ static bool check_subset(const float*, const float*) { return true; }
   __device__ static int solve(const ModelParams& P, const float* ms1, const float* ms2, double* model, double* ws) {
@@ -928,6 +934,7 @@ __device__ GL_NOINLINE int em_solve5(const double* q1, const double* q2, double*
 struct EModel {
   static constexpr int MP = 5, MAXM = 10, MS = 9, PT1 = 2, PT2 = 2;
   static constexpr int CH = 64, WS = 0;  // initialisation only (src/initializer.cpp), not on the per-frame path: private memory
+  static constexpr bool WIDE = true;
   static constexpr int LMEDS_BELOW = 0;
   __device__ static bool check_subset(const float*, const float*) { return true; }
   __device__ static int solve(const ModelParams& P, const float* ms1, const float* ms2, double* models, double*) {
