@@ -183,26 +183,37 @@ __device__ __forceinline__ bool has9(unsigned m) {
   return (x & 0xFFFFu) != 0;
 }
 
-__device__ __forceinline__ int fast_score_px(const u8* c, int t) {
-  // circle offsets (dx,dy) k=0..15 as in fast_score.cpp makeOffsets(16)
+// differences centre - circle pixel, circle offsets (dx,dy) k=0..15 as in fast_score.cpp makeOffsets(16)
+__device__ __forceinline__ void fast_ring(const u8* c, int (&d)[25]) {
   const int v = c[0];
-  int d[25];
   d[0] = v - c[3 * FT_P + 0];   d[1] = v - c[3 * FT_P + 1];   d[2] = v - c[2 * FT_P + 2];
   d[3] = v - c[1 * FT_P + 3];   d[4] = v - c[3];              d[5] = v - c[-1 * FT_P + 3];
   d[6] = v - c[-2 * FT_P + 2];  d[7] = v - c[-3 * FT_P + 1];  d[8] = v - c[-3 * FT_P + 0];
   d[9] = v - c[-3 * FT_P - 1];  d[10] = v - c[-2 * FT_P - 2]; d[11] = v - c[-1 * FT_P - 3];
   d[12] = v - c[-3];            d[13] = v - c[1 * FT_P - 3];  d[14] = v - c[2 * FT_P - 2];
   d[15] = v - c[3 * FT_P - 1];
+}
+
+// FAST-9: an arc of 9 contiguous circle pixels all darker than v - t or all brighter than v + t
+__device__ __forceinline__ bool fast_is_corner(const u8* c, int t) {
+  int d[25];
+  fast_ring(c, d);
   unsigned mdark = 0, mbright = 0;  // dark: p < v - t  <=> d > t ; bright: p > v + t <=> d < -t
 #pragma unroll
   for (int k = 0; k < 16; k++) {
     mdark |= (unsigned)(d[k] > t) << k;
     mbright |= (unsigned)(d[k] < -t) << k;
   }
-  if (!has9(mdark) && !has9(mbright)) return 0;
+  return has9(mdark) || has9(mbright);
+}
+
+// cornerScore<16> of a pixel that passed fast_is_corner: max(t, max_arc min d, max_arc min(-d)) - 1 over the 16 arcs
+// of 9 contiguous pixels
+__device__ __forceinline__ int fast_corner_score(const u8* c, int t) {
+  int d[25];
+  fast_ring(c, d);
 #pragma unroll
   for (int k = 16; k < 25; k++) d[k] = d[k - 16];
-  // cornerScore<16>: max(t, max_arc min d, max_arc min(-d)) - 1 over the 16 arcs of 9 contiguous pixels
   int mn2[24], mx2[24], mn4[22], mx4[22], mn8[18], mx8[18];
 #pragma unroll
   for (int k = 0; k < 24; k++) { mn2[k] = min(d[k], d[k + 1]); mx2[k] = max(d[k], d[k + 1]); }
@@ -253,13 +264,17 @@ struct FastArgs {
 };
 
 // FAST-9/16 + cornerScore + strict 3x3 NMS for one 64x32 tile, plus the per-row survivor counts of the ordered
-// compaction.  Phase 1 rejects with the 4-point pre-test, 4 pixels per lane from aligned LDS dwords; phase 2 runs the
-// 16-pixel test and cornerScore for the compacted candidates (dense lanes); phase 3 is the NMS, 4 pixels per lane.
+// compaction.  Phase 1 rejects with the 4-point pre-test, 4 pixels per lane from aligned LDS dwords (about 5 % pass);
+// phase 2a runs the 16-pixel arc test on the compacted candidates and compacts the corners (about 2 % of the pixels),
+// phase 2b scores those, phase 3 is the NMS of the corners (list driven, not a pass over the tile), phase 4 writes the
+// survivors of each tile row in x order.
 __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs A) {
   __shared__ unsigned s_px[FT_PR * FT_PD];
   __shared__ unsigned s_sc[FT_SR * FT_PD];
   __shared__ unsigned short s_list[FT_SR * (FT_W + 2) + 64];
-  __shared__ int s_n;
+  __shared__ unsigned short s_list2[FT_SR * (FT_W + 2) + 64];
+  __shared__ unsigned s_rowmask[FT_H][2];
+  __shared__ int s_n, s_n2;
   int bx, by, bz;
   if (!xcd_tile(A.tg, bx, by, bz)) return;
   const u8* sp = A.pyr + (size_t)bz * A.slot_stride + A.off;
@@ -270,7 +285,8 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs A) {
   // tiles that cannot contain a needed score
   const bool dead = x0 + FT_W + 1 <= lo || x0 - 1 >= w - lo || y0 + FT_H + 1 <= lo || y0 - 1 >= h - lo;
   if (dead) return;  // seg_cnt / row_cnt are zeroed before the launch
-  if (tid == 0) s_n = 0;
+  if (tid == 0) { s_n = 0; s_n2 = 0; }
+  if (tid < 2 * FT_H) s_rowmask[tid >> 1][tid & 1] = 0u;
   // ---- phase 0: pixel tile rows y0-4 .. y0+35, columns x0-4 .. x0+67 ----------------------------------------------------
   const bool interior = x0 >= 4 && x0 + 68 <= w && y0 >= 4 && y0 + FT_H + 4 <= h;
   if (interior) {
@@ -331,68 +347,71 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs A) {
     }
   }
   __syncthreads();
-  // ---- phase 2: full 16-pixel test + cornerScore for the candidates only (dense lanes) -----------------------------------
+  // ---- phase 2a: the 16-pixel arc test for the candidates (about 5 % of the pixels); corners are compacted again -------
   {
     const int n = s_n;
     const u8* pb = (const u8*)s_px;
-    u8* sb = (u8*)s_sc;
-    for (int k = tid; k < n; k += 256) {
-      const int code = s_list[k];
-      const int sy = code >> 7, c = code & 127;
-      const int sc = fast_score_px(pb + __umul24(sy + 3, FT_P) + c, A.threshold);
-      sb[__umul24(sy, FT_P) + c] = (u8)sc;
+    for (int k0 = 0; k0 < n; k0 += 256) {
+      const int k = k0 + tid;
+      int code = 0;
+      bool corner = false;
+      if (k < n) {
+        code = s_list[k];
+        corner = fast_is_corner(pb + __umul24((code >> 7) + 3, FT_P) + (code & 127), A.threshold);
+      }
+      const unsigned long long m = __ballot(corner);
+      int base = 0;
+      if (lane == 0 && m) base = atomicAdd(&s_n2, __popcll(m));
+      base = __shfl(base, 0, 64);
+      if (corner) s_list2[base + __popcll(m & ((1ull << lane) - 1))] = (unsigned short)code;
     }
   }
   __syncthreads();
-  // ---- phase 3: strict 3x3 NMS, 4 pixels per item, one dword store; per-row survivor counts ----------------------------
-  for (int it = tid; it < FT_H * 16; it += 256) {
-    const int r = it >> 4, g = (it & 15) + 1;
-    const int gy = y0 + r, gx = x0 + 4 * (g - 1);
-    const unsigned* c = s_sc + __umul24(r + 1, FT_PD) + g;
-    ft_us2 nlo, nhi;  // running maximum of the 8 neighbours
-    {
-      const unsigned L = c[-1], C = c[0], R = c[1];
-      const unsigned a = __builtin_amdgcn_alignbyte(C, L, 3), b = __builtin_amdgcn_alignbyte(R, C, 1);
-      nlo = ft_max(ft_lo(a), ft_lo(b)); nhi = ft_max(ft_hi(a), ft_hi(b));
+  // ---- phase 2b: cornerScore for the corners only (about 2 % of the pixels: usually a single dense wavefront) ---------
+  const int n2 = s_n2;
+  {
+    const u8* pb = (const u8*)s_px;
+    u8* sb = (u8*)s_sc;
+    for (int k = tid; k < n2; k += 256) {
+      const int code = s_list2[k];
+      const int sy = code >> 7, c = code & 127;
+      sb[__umul24(sy, FT_P) + c] = (u8)fast_corner_score(pb + __umul24(sy + 3, FT_P) + c, A.threshold);
     }
-#pragma unroll
-    for (int q = -1; q <= 1; q += 2) {
-      const unsigned L = c[q * FT_PD - 1], C = c[q * FT_PD], R = c[q * FT_PD + 1];
-      const unsigned a = __builtin_amdgcn_alignbyte(C, L, 3), b = __builtin_amdgcn_alignbyte(R, C, 1);
-      nlo = ft_max(nlo, ft_max(ft_lo(C), ft_max(ft_lo(a), ft_lo(b))));
-      nhi = ft_max(nhi, ft_max(ft_hi(C), ft_max(ft_hi(a), ft_hi(b))));
+  }
+  __syncthreads();
+  // ---- phase 3: strict 3x3 NMS of the corners inside the tile and the compaction band; survivors as row bit masks ------
+  {
+    const u8* sb = (const u8*)s_sc;
+    for (int k = tid; k < n2; k += 256) {
+      const int code = s_list2[k];
+      const int sy = code >> 7, c = code & 127;
+      const int r = sy - 1, x = c - 4;                       // tile coordinates
+      const int gy = y0 + r, gx = x0 + x;
+      if (r < 0 || r >= FT_H || x < 0 || x >= FT_W) continue;  // halo corners only serve as neighbours
+      if (gy < A.edge || gy >= h - A.edge || gx < A.edge || gx >= w - A.edge) continue;
+      const u8* q = sb + __umul24(sy, FT_P) + c;
+      const int v = q[0];
+      int nb = max(max((int)q[-1], (int)q[1]), max((int)q[-FT_P], (int)q[FT_P]));
+      nb = max(nb, max(max((int)q[-FT_P - 1], (int)q[-FT_P + 1]), max((int)q[FT_P - 1], (int)q[FT_P + 1])));
+      if (v > nb) atomicOr(&s_rowmask[r][x >> 5], 1u << (x & 31));
     }
-    const unsigned C1 = c[0];
-    const ft_s2 vlo = __builtin_bit_cast(ft_s2, ft_lo(C1)), vhi = __builtin_bit_cast(ft_s2, ft_hi(C1));
-    // keep where v > max(neighbours): (max - v) negative; v > max >= 0 also makes v non-zero
-    const ft_s2 klo = (__builtin_bit_cast(ft_s2, nlo) - vlo) >> 15, khi = (__builtin_bit_cast(ft_s2, nhi) - vhi) >> 15;
-    const unsigned olo = __builtin_bit_cast(unsigned, vlo) & __builtin_bit_cast(unsigned, klo);
-    const unsigned ohi = __builtin_bit_cast(unsigned, vhi) & __builtin_bit_cast(unsigned, khi);
-    unsigned out = __builtin_amdgcn_perm(ohi, olo, 0x06040200u);
-    // Survivors inside the compaction band go out as (x in tile, score) records at the head of this row segment's 64
-    // bytes of the score plane - strict NMS leaves at most 32 per 64 pixels - with their count in seg_cnt: the dense
-    // map is never written, and the emit pass reads counts and records only.
-    const bool row_in = gy >= A.edge && gy < h - A.edge;
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-      if (!row_in || gx + j < A.edge || gx + j >= w - A.edge) out &= ~(0xFFu << (8 * j));
-    int cnt = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) cnt += ((out >> (8 * j)) & 0xFFu) != 0;
-    const int own = cnt;
-    cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x111, 0xf, 0xf, true);  // row_shr:1   inclusive prefix over the 16 lanes
-    cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x112, 0xf, 0xf, true);  // row_shr:2   that share this row segment
-    cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x114, 0xf, 0xf, true);  // row_shr:4
-    cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x118, 0xf, 0xf, true);  // row_shr:8
-    if (own) {
-      unsigned short* rec = (unsigned short*)(dp + (size_t)__umul24(gy, pitch) + x0) + (cnt - own);
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const unsigned sc = (out >> (8 * j)) & 0xFFu;
-        if (sc) *rec++ = (unsigned short)(((unsigned)(4 * (g - 1) + j) << 8) | sc);
+  }
+  __syncthreads();
+  // ---- phase 4: per tile row, survivors in x order as (x in tile, score) records at the head of this row segment's 64
+  // bytes of the score plane - strict NMS leaves at most 32 per 64 pixels - with their count in seg_cnt: the dense map is
+  // never written, and the emit pass reads counts and records only.
+  if (tid < FT_H) {
+    const int r = tid, gy = y0 + r;
+    unsigned long long m = (unsigned long long)s_rowmask[r][0] | ((unsigned long long)s_rowmask[r][1] << 32);
+    const int cnt = __popcll(m);
+    if (cnt) {
+      const u8* sb = (const u8*)s_sc + __umul24(r + 1, FT_P) + 4;
+      unsigned short* rec = (unsigned short*)(dp + (size_t)__umul24(gy, pitch) + x0);
+      while (m) {
+        const int x = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        *rec++ = (unsigned short)(((unsigned)x << 8) | sb[x]);
       }
-    }
-    if ((tid & 15) == 15 && cnt > 0) {
       const size_t rowi = (size_t)bz * A.max_rows + A.row_first + (gy - A.edge);
       A.seg_cnt[rowi * A.seg_per_row + bx] = (u8)cnt;
       atomicAdd(A.row_cnt + rowi, cnt);
