@@ -288,16 +288,35 @@ __global__ __launch_bounds__(RB_T) void orb_select_kernel(OrbSelArgs A) {
   if (tid == 0) A.kept[slot * MVO_ORB_LEVELS + l] = m;
 }
 
-// kp_base[s] = sum of kept counts of the slots before s (one small block; B <= a few thousand)
-__global__ void orb_sel_scan_kernel(const int* __restrict__ kept, int nslots, int nlevels, int* __restrict__ kp_base) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    int run = 0;
-    for (int s = 0; s < nslots; s++) {
-      kp_base[s] = run;
-      for (int l = 0; l < nlevels; l++) run += kept[s * MVO_ORB_LEVELS + l];
+// kp_base[s] = sum of kept counts of the slots before s: one block, a chunk of 256 slots per pass (a slot per thread,
+// LDS Hillis-Steele scan, running carry)
+__global__ __launch_bounds__(256) void orb_sel_scan_kernel(const int* __restrict__ kept, int nslots, int nlevels, int* __restrict__ kp_base) {
+  __shared__ int s_scan[2][256];
+  __shared__ int s_carry;
+  const int tid = threadIdx.x;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int s0 = 0; s0 < nslots; s0 += 256) {
+    const int s = s0 + tid;
+    int own = 0;
+    if (s < nslots)
+      for (int l = 0; l < nlevels; l++) own += kept[s * MVO_ORB_LEVELS + l];
+    int cur = 0;
+    s_scan[0][tid] = own;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+      const int v = s_scan[cur][tid] + (tid >= d ? s_scan[cur][tid - d] : 0);
+      s_scan[cur ^ 1][tid] = v;
+      cur ^= 1;
+      __syncthreads();
     }
-    kp_base[nslots] = run;
+    const int incl = s_scan[cur][tid], carry = s_carry;
+    if (s < nslots) kp_base[s] = carry + incl - own;
+    __syncthreads();
+    if (tid == 255) s_carry = carry + incl;
+    __syncthreads();
   }
+  if (tid == 0) kp_base[nslots] = s_carry;
 }
 
 // dense selection list: slot-major, levels in order, each level in retainBest's order
@@ -324,7 +343,7 @@ int orb_select_device(mvo_ctx* ctx, const OrbGeom& G, int nslots) {
   for (int l = 0; l < MVO_ORB_LEVELS; l++) A.quota[l] = G.quota[l];
   A.cand_cap = o->cand_cap;
   hipLaunchKernelGGL(orb_select_kernel, dim3(G.nlevels, nslots), dim3(RB_T), 0, ctx->stream, A);
-  hipLaunchKernelGGL(orb_sel_scan_kernel, dim3(1), dim3(64), 0, ctx->stream, o->d_kept, nslots, G.nlevels, o->d_kp_base);
+  hipLaunchKernelGGL(orb_sel_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, o->d_kept, nslots, G.nlevels, o->d_kp_base);
   hipLaunchKernelGGL(orb_sel_gather_kernel, dim3(G.nlevels, nslots), dim3(256), 0, ctx->stream, o->d_wk, o->d_lvl_cnt, o->d_slot_base,
                      o->d_kept, o->d_kp_base, o->kp_cap, o->d_sel);
   return MVO_OK;
