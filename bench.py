@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="independent camera streams per GPU")
+    ap.add_argument("--batch", type=int, default=512, help="independent camera streams per GPU (256: 25.3k fps, 512: 26.8k, 1024: 27.5k)")
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--nfeatures", type=int, default=2000)
