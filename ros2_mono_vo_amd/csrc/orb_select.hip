@@ -261,14 +261,20 @@ struct OrbSelArgs {
   int cand_cap;
 };
 
+// Levels with at most RB_LDS_CAP candidates (at 720p: all of them, level 0 has ~2-3 k) keep the (response, index) array
+// in LDS for both passes: every introselect round is a handful of dependent passes over it, and from LDS a round
+// costs a fraction of the L2 round trips (the rank-swap staging buffers stay in global memory).
+#define RB_LDS_CAP 4096
 __global__ __launch_bounds__(RB_T) void orb_select_kernel(OrbSelArgs A) {
   __shared__ RbShared S;
+  __shared__ uint2 s_a[RB_LDS_CAP];
   const int slot = blockIdx.y, l = blockIdx.x, tid = threadIdx.x;
   int off = A.slot_base[slot];
   for (int k = 0; k < l; k++) off += A.lvl_cnt[slot * MVO_ORB_LEVELS + k];
   int cnt = A.lvl_cnt[slot * MVO_ORB_LEVELS + l];
   if (off + cnt > A.cand_cap) cnt = max(0, A.cand_cap - off);  // capacity overrun is reported by the host from the counts
-  uint2* a = A.wk + off;
+  const bool in_lds = cnt <= RB_LDS_CAP;
+  uint2* a = in_lds ? s_a : A.wk + off;
   for (int i = tid; i < cnt; i += RB_T) a[i] = make_uint2(__float_as_uint((float)A.cs[off + i]), (unsigned)(off + i));
   __syncthreads();
   int m = rb_retain_best(a, cnt, 2 * A.quota[l], A.stL + off, A.stR + off, S, -1);
@@ -285,6 +291,10 @@ __global__ __launch_bounds__(RB_T) void orb_select_kernel(OrbSelArgs A) {
   }
   __syncthreads();
   m = rb_retain_best(a, m, A.quota[l], A.stL + off, A.stR + off, S, -1);
+  if (in_lds) {
+    __syncthreads();
+    for (int i = tid; i < m; i += RB_T) A.wk[off + i] = a[i];   // the gather pass reads the survivors from wk
+  }
   if (tid == 0) A.kept[slot * MVO_ORB_LEVELS + l] = m;
 }
 
