@@ -130,12 +130,12 @@ def main():
     t0 = time.perf_counter()
     lk_points = 0
     last = None
-    step_ms, step_stage, prev_cum = [], [], {}
+    step_ms, step_stage, prev_cum, results = [], [], {}, []
     for k in range(K):
         ts = time.perf_counter()
         last = ctx.batch_step(1 + Wm + k, stages)   # synchronous: returns when the step's results are on the host
         step_ms.append(round((time.perf_counter() - ts) * 1e3, 3))
-        lk_points += sum(r.n_prev for r in last)
+        results.append(last)
         if args.per_step:
             cum = {n: ctx.profile_read(n)[0] for n in STAGE_TIMERS}
             step_stage.append({n: round(cum[n] - prev_cum.get(n, 0.0), 3) for n in STAGE_TIMERS})
@@ -146,6 +146,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     ctx.profile_enable(False)
+    lk_points = sum(r.n_prev for res in results for r in res)   # bookkeeping for the roofline, outside the timed region
     dt = parallel.max_over_ranks(dt, dist, device="cuda")
 
     prof = {}

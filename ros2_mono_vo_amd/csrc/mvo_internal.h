@@ -128,6 +128,7 @@ struct OrbState {
   int kp_cap = 0;  // dense, whole batch
   int* d_sel = nullptr;  // selected candidate indices
   mvo_keypoint* d_kp = nullptr;
+  void* d_brec = nullptr;  // [kp_cap] rBRIEF records (orb.hip BriefRec), written by the IC-angle kernel
   u8* d_desc = nullptr;
   char4* d_pattern = nullptr;
   unsigned* d_icmask = nullptr;  // [16][9] byte masks of the IC-angle disc rows

@@ -561,6 +561,15 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
 // nine (misaligned) dwords, masks the bytes outside the disc (|u| <= umax[|dy|]; masks tabulated per |dy|) and gets
 // the row sum and the (u + 16)-weighted row sum with two v_dot4_u32_u8 per dword.  Integer moments: any summation
 // order gives OpenCV's m_10 / m_01 (orb.cpp IC_Angle).
+// What rBRIEF needs of a key-point, prepared where its angle is computed: the byte offset of its centre in the blurred
+// pyramid, the level's pitch and the rotation - one 32-byte record instead of the sel -> cl / cslot / kp load chain.
+struct __attribute__((aligned(16))) BriefRec {
+  unsigned long long off;
+  int pitch;
+  float a, b;   // cos, sin of the orientation, float(cos(double)) like OpenCV's computeOrbDescriptors
+  int pad[3];
+};
+
 __global__ __launch_bounds__(256) void ic_angle_kernel(const u8* __restrict__ pyr, OrbGeom G, const int* __restrict__ sel,
                                                        int nsel, const unsigned short* __restrict__ cx,
                                                        const unsigned short* __restrict__ cy, const u8* __restrict__ cl,
@@ -576,12 +585,18 @@ __global__ __launch_bounds__(256) void ic_angle_kernel(const u8* __restrict__ py
     if (sub < 31) {
       const int dy = sub - ORB_HALF, ady = dy < 0 ? -dy : dy;
       const int pitch = G.pitch[l];
-      const unsigned* q = (const unsigned*)(pyr + (size_t)cslot[ci] * G.slot_stride + G.off[l] + (size_t)__mul24(y0 + dy, pitch) + x0 - 16);
+      // bytes x0-16 .. x0+19 of the row: three aligned 16-byte loads (one lane address each on the texture path instead
+      // of nine), re-phased with v_alignbyte
+      const u8* base = pyr + (size_t)cslot[ci] * G.slot_stride + G.off[l] + (size_t)__mul24(y0 + dy, pitch) + x0 - 16;
+      const int sh = (int)((size_t)base & 3);
+      const uint4* q4 = (const uint4*)(base - sh);
+      const uint4 v0 = q4[0], v1 = q4[1], v2 = q4[2];
+      const unsigned w[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
       const unsigned* mk = icmask + ady * 9;
       unsigned rs = 0, ws = 0;
 #pragma unroll
       for (int j = 0; j < 9; j++) {
-        const unsigned d = q[j] & mk[j];
+        const unsigned d = __builtin_amdgcn_alignbyte(w[j + 1], w[j], sh) & mk[j];
         const unsigned wt = (unsigned)(4 * j) * 0x01010101u + 0x03020100u;   // weights u + 16 = byte index 4j .. 4j+3
         rs = __builtin_amdgcn_udot4(d, 0x01010101u, rs, false);
         ws = __builtin_amdgcn_udot4(d, wt, ws, false);
@@ -694,34 +709,68 @@ __global__ __launch_bounds__(256) void blur7_kernel(const u8* __restrict__ pyr, 
 // ---------------------------------------------------------------------------------------------------
 // rotated BRIEF: 2 key-points per wavefront, one descriptor byte per lane
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void brief_kernel(const u8* __restrict__ blur, OrbGeom G, const int* __restrict__ sel,
-                                                    int nsel, const u8* __restrict__ cl, const int* __restrict__ cslot,
-                                                    const mvo_keypoint* __restrict__ kp, const char4* __restrict__ pattern,
-                                                    u8* __restrict__ desc) {
-  __shared__ char4 s_pat[256];
-  s_pat[threadIdx.x] = pattern[threadIdx.x];
-  __syncthreads();
-  const int k = blockIdx.x * 8 + (threadIdx.x >> 5);
-  const int byte = threadIdx.x & 31;
+// One lane per key-point: the records rBRIEF works from (64 sin / cos pairs per wavefront instead of one per half-wave).
+__global__ __launch_bounds__(256) void brief_rec_kernel(OrbGeom G, const int* __restrict__ sel, int nsel, const u8* __restrict__ cl,
+                                                        const int* __restrict__ cslot, const mvo_keypoint* __restrict__ kp,
+                                                        BriefRec* __restrict__ rec) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= nsel) return;
-  const int ci = sel[k];
-  const int l = cl[ci];
+  const int ci = sel[k], l = cl[ci];
   const mvo_keypoint kpt = kp[k];
-  const int pitch = G.pitch[l];
-  float scale = 1.f / G.scale[l];
+  // computeOrbDescriptors: centre = cvRound(kpt.pt * (1 / scale)) in the level image, angle in radians as float
+  const float scale = 1.f / G.scale[l];
+  const int ccx = d_cv_round(kpt.x * scale), ccy = d_cv_round(kpt.y * scale);
   float angle = kpt.angle;
   angle *= (float)(M_PI / 180.f);
-  float a = (float)cos((double)angle), b = (float)sin((double)angle);
-  int ccx = d_cv_round(kpt.x * scale), ccy = d_cv_round(kpt.y * scale);
-  const u8* c = blur + (size_t)cslot[ci] * G.slot_stride + G.off[l] + (size_t)ccy * pitch + ccx;
+  BriefRec r;
+  r.off = (unsigned long long)((size_t)cslot[ci] * G.slot_stride + G.off[l] + (size_t)ccy * G.pitch[l] + ccx);
+  r.pitch = G.pitch[l];
+  r.a = (float)cos((double)angle);
+  r.b = (float)sin((double)angle);
+  r.pad[0] = r.pad[1] = r.pad[2] = 0;
+  rec[k] = r;
+}
+
+// 32 lanes per key-point, one descriptor byte per lane.  The rotated pattern stays within +-19 pixels of the centre
+// (|p| <= 13 * sqrt(2)), so the 39 x 48-byte neighbourhood is staged in LDS with 16-byte loads first: the texture path
+// serves about one lane address per cycle and CU, and 512 byte gathers per key-point made the kernel bound by it
+// (117 wide loads now); the 16 taps of a lane are LDS byte reads.
+#define BR_R 19
+#define BR_ROWS (2 * BR_R + 1)
+#define BR_LP 64   // LDS row pitch in bytes: 48 staged + pad, keeps the 16-byte stores aligned
+__global__ __launch_bounds__(256) void brief_kernel(const u8* __restrict__ blur, const BriefRec* __restrict__ rec, int nsel,
+                                                    const char4* __restrict__ pattern, u8* __restrict__ desc) {
+  __shared__ char4 s_pat[256];
+  __shared__ uint4 s_patch[8][BR_ROWS * BR_LP / 16];
+  s_pat[threadIdx.x] = pattern[threadIdx.x];
+  const int h = threadIdx.x >> 5, byte = threadIdx.x & 31;
+  const int k = blockIdx.x * 8 + h;
+  const bool live = k < nsel;
+  BriefRec r;
+  r.off = 0; r.pitch = 0; r.a = 0.f; r.b = 0.f;
+  int shift = 0;
+  if (live) {
+    r = rec[k];
+    const u8* base = blur + r.off - (size_t)BR_R * r.pitch - BR_R;   // key-points keep 31 px from the border: in range
+    shift = (int)((size_t)base & 3);
+    const u8* ab = base - shift;
+    for (int i = byte; i < BR_ROWS * 3; i += 32) {
+      const int row = i / 3, q = i - row * 3;
+      s_patch[h][row * (BR_LP / 16) + q] = *(const uint4*)(ab + (size_t)row * r.pitch + 16 * q);
+    }
+  }
+  __syncthreads();
+  if (!live) return;
+  const float a = r.a, b = r.b;
+  const u8* c = (const u8*)s_patch[h] + BR_R * BR_LP + BR_R + shift;
   int val = 0;
 #pragma unroll
   for (int t = 0; t < 8; t++) {
     char4 p = s_pat[byte * 8 + t];
     float x0 = p.x * a - p.y * b, y0 = p.x * b + p.y * a;
     float x1 = p.z * a - p.w * b, y1 = p.z * b + p.w * a;
-    int t0 = c[d_cv_round(y0) * pitch + d_cv_round(x0)];
-    int t1 = c[d_cv_round(y1) * pitch + d_cv_round(x1)];
+    int t0 = c[d_cv_round(y0) * BR_LP + d_cv_round(x0)];
+    int t1 = c[d_cv_round(y1) * BR_LP + d_cv_round(x1)];
     val |= (t0 < t1) << t;
   }
   desc[(size_t)k * 32 + byte] = (u8)val;
@@ -771,6 +820,7 @@ int orb_state_create(mvo_ctx* ctx) {
   o->kp_cap = ctx->maxpts * ctx->B;
   MVO_HIP(hipMalloc(&o->d_sel, (size_t)o->kp_cap * sizeof(int)));
   MVO_HIP(hipMalloc(&o->d_kp, (size_t)o->kp_cap * sizeof(mvo_keypoint)));
+  MVO_HIP(hipMalloc(&o->d_brec, (size_t)o->kp_cap * sizeof(BriefRec)));
   MVO_HIP(hipMalloc(&o->d_desc, (size_t)o->kp_cap * 32));
   MVO_HIP(hipMalloc(&o->d_pattern, 256 * sizeof(char4)));
   {
@@ -815,7 +865,7 @@ void orb_state_destroy(mvo_ctx* ctx) {
   OrbState* o = ctx->orb;
   if (!o) return;
   void* dev[] = {o->d_pyr, o->d_score, o->d_blur, o->d_seg_cnt, o->d_row_cnt, o->d_row_off, o->d_lvl_cnt, o->d_slot_tot,
-                 o->d_slot_base, o->d_cx, o->d_cy, o->d_cs, o->d_cl, o->d_cslot, o->d_ch, o->d_sel, o->d_kp,
+                 o->d_slot_base, o->d_cx, o->d_cy, o->d_cs, o->d_cl, o->d_cslot, o->d_ch, o->d_sel, o->d_kp, o->d_brec,
                  o->d_desc, o->d_pattern, o->d_wk, o->d_stl, o->d_str, o->d_kept, o->d_kp_base, o->d_rtab, o->d_icmask};
   for (void* p : dev) (void)hipFree(p);
   void* hst[] = {o->h_counts, o->h_kp, o->h_desc};
@@ -974,8 +1024,10 @@ int orb_describe_enqueue(mvo_ctx* ctx, int w, int h, int nslots, bool describe, 
     hipLaunchKernelGGL(ic_angle_kernel, dim3((nsel + 7) / 8), dim3(256), 0, st, o->d_pyr, G, o->d_sel, nsel, o->d_cx, o->d_cy,
                        o->d_cl, o->d_cslot, o->d_ch, o->d_icmask, o->d_kp);
     if (describe)
-      hipLaunchKernelGGL(brief_kernel, dim3((nsel + 7) / 8), dim3(256), 0, st, o->d_blur, G, o->d_sel, nsel, o->d_cl, o->d_cslot,
-                         o->d_kp, o->d_pattern, o->d_desc);
+      hipLaunchKernelGGL(brief_rec_kernel, dim3((nsel + 255) / 256), dim3(256), 0, st, G, o->d_sel, nsel, o->d_cl, o->d_cslot, o->d_kp,
+                         (BriefRec*)o->d_brec);
+      hipLaunchKernelGGL(brief_kernel, dim3((nsel + 7) / 8), dim3(256), 0, st, o->d_blur,
+                         (const BriefRec*)o->d_brec, nsel, o->d_pattern, o->d_desc);
   }
   if (to_host) {
     if (describe) MVO_HIP(hipMemcpyAsync(o->h_desc, o->d_desc, (size_t)nsel * 32, hipMemcpyDeviceToHost, st));
