@@ -113,10 +113,10 @@ struct LkArgs {
 
 #define LK_WIN 21
 #define LK_IT 24          // I tile edge (WIN + 1 bilinear + 2 Scharr halo)
-#define LK_IP 28          // I tile pitch: 7 dwords cover 24 bytes at any 4-byte phase
+#define LK_IP 36          // I tile pitch: two 16-byte loads cover 24 bytes at any 4-byte phase; 9 dwords (odd: rows spread over banks)
 #define LK_DT 22          // derivative tile edge
 #define LK_JT 32          // J tile edge
-#define LK_JP 36          // J tile pitch: 9 dwords cover 32 bytes at any 4-byte phase
+#define LK_JP 52          // J tile pitch: three 16-byte loads cover 32 bytes at any 4-byte phase; 13 dwords
 #define LK_JSLACK ((LK_JT - (LK_WIN + 1)) / 2)
 
 typedef short lk_short2 __attribute__((ext_vector_type(2)));
@@ -172,23 +172,26 @@ __device__ __forceinline__ void lk_weights(float a, float b, int& w00, int& w01,
 __device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
 
 struct LkWaveLds {
-  unsigned it[LK_IT * LK_IP / 4];   // previous-image neighbourhood (rows of 28 bytes)
+  unsigned it[LK_IT * LK_IP / 4];   // previous-image neighbourhood (rows of LK_IP bytes)
   short2 dt[LK_DT * LK_DT];         // Scharr (dx, dy)
-  unsigned jt[LK_JT * LK_JP / 4];   // next-image search tile (rows of 36 bytes)
+  unsigned jt[LK_JT * LK_JP / 4];   // next-image search tile (rows of LK_JP bytes)
 };
 
-// Stage ROWS x TW bytes of the image starting at (x0, y0) into LDS rows of NDW dwords.  Fast path: the
-// tile lies inside the image -> aligned dword loads, the tile starts `shift` bytes into each LDS row.
-// Slow path (image border): per-byte reflect-101.  Returns the byte shift (wave-uniform).
-template <int ROWS, int TW, int NDW>
+// Stage ROWS x TW bytes of the image starting at (x0, y0) into LDS rows of PD dwords.  Fast path: the tile lies inside
+// the image -> NX4 aligned 16-byte loads per row (a lane address on the texture path costs the same for 4 or 16
+// bytes), the tile starts `shift` bytes into each LDS row.  Slow path (image border): per-byte reflect-101.  Returns
+// the byte shift (wave-uniform).
+template <int ROWS, int TW, int PD, int NX4>
 __device__ __forceinline__ int lk_load_tile(unsigned* lds, const u8* __restrict__ img, int w, int h, int pitch, int x0, int y0, int lane) {
   const int xa = x0 & ~3;
-  const bool inside = x0 >= 0 && y0 >= 0 && x0 + TW <= w && y0 + ROWS <= h && xa + 4 * NDW <= pitch;
+  const bool inside = x0 >= 0 && y0 >= 0 && x0 + TW <= w && y0 + ROWS <= h && xa + 16 * NX4 <= pitch;
   if (inside) {
     const u8* base = img + (size_t)y0 * pitch + xa;
-    for (int i = lane; i < ROWS * NDW; i += 64) {
-      int row = i / NDW, k = i - row * NDW;
-      lds[i] = *(const unsigned*)(base + (size_t)row * pitch + 4 * k);
+    for (int i = lane; i < ROWS * NX4; i += 64) {
+      const int row = i / NX4, k = i - row * NX4;
+      const uint4 v = *(const uint4*)(base + (size_t)row * pitch + 16 * k);
+      unsigned* d = lds + row * PD + 4 * k;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
     return x0 - xa;
   }
@@ -196,7 +199,7 @@ __device__ __forceinline__ int lk_load_tile(unsigned* lds, const u8* __restrict_
   for (int i = lane; i < ROWS * TW; i += 64) {
     int row = i / TW, col = i - row * TW;
     int gx = d_reflect101(x0 + col, w), gy = d_reflect101(y0 + row, h);
-    lb[row * (NDW * 4) + col] = img[(size_t)gy * pitch + gx];
+    lb[row * (PD * 4) + col] = img[(size_t)gy * pitch + gx];
   }
   return 0;
 }
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs A) {
     }
     // ---- stage the 24x24 neighbourhood of I (origin ipx-1, ipy-1) -------------------------------------
     __builtin_amdgcn_wave_barrier();
-    const int shI = lk_load_tile<LK_IT, LK_IT, LK_IP / 4>(S.it, I, lv.w, lv.h, lv.pitch, ipx - 1, ipy - 1, lane);
+    const int shI = lk_load_tile<LK_IT, LK_IT, LK_IP / 4, 2>(S.it, I, lv.w, lv.h, lv.pitch, ipx - 1, ipy - 1, lane);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // ---- Scharr field on the 22x22 window-source positions (zero outside the image) --------------
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs A) {
       if (!have_tile || ddx < 0 || ddx > LK_JT - (LK_WIN + 1) || ddy < 0 || ddy > LK_JT - (LK_WIN + 1)) {
         jx0 = inx - LK_JSLACK; jy0 = iny - LK_JSLACK;
         __builtin_amdgcn_wave_barrier();
-        shJ = lk_load_tile<LK_JT, LK_JT, LK_JP / 4>(S.jt, J, lv.w, lv.h, lv.pitch, jx0, jy0, lane);
+        shJ = lk_load_tile<LK_JT, LK_JT, LK_JP / 4, 3>(S.jt, J, lv.w, lv.h, lv.pitch, jx0, jy0, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         have_tile = true;
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs A) {
         if (!have_tile || ddx < 0 || ddx > LK_JT - (LK_WIN + 1) || ddy < 0 || ddy > LK_JT - (LK_WIN + 1)) {
           jx0 = inx - LK_JSLACK; jy0 = iny - LK_JSLACK;
           __builtin_amdgcn_wave_barrier();
-          shJ = lk_load_tile<LK_JT, LK_JT, LK_JP / 4>(S.jt, J, lv.w, lv.h, lv.pitch, jx0, jy0, lane);
+          shJ = lk_load_tile<LK_JT, LK_JT, LK_JP / 4, 3>(S.jt, J, lv.w, lv.h, lv.pitch, jx0, jy0, lane);
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           ddx = LK_JSLACK; ddy = LK_JSLACK;
