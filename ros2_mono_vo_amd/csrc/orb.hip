@@ -132,11 +132,18 @@ __global__ __launch_bounds__(256) void resize_exact_kernel(const u8* __restrict_
   {
     // 32 lanes per tile row (24 dwords at most), 8 rows per pass: no division, 32-bit multiplies kept off the path
     // (v_mul_lo_u32 / v_mad_u64_u32 are quarter rate on CDNA)
-    const int k = tid & 31;
-    const u8* gp = sp + (size_t)__umul24(sy0 + (tid >> 5), spitch) + sxa + 4 * k;
-    unsigned* lp = s_src + __umul24(tid >> 5, RZ_SP / 4) + k;
-    if (k < ndw)
-      for (int ty = tid >> 5; ty < nrow; ty += 8, gp += 8 * (size_t)spitch, lp += 8 * (RZ_SP / 4)) *lp = *(const unsigned*)gp;
+    // rows come in as 16-byte loads, 8 lanes per row (a lane address costs the same for 4 or 16 bytes); a group that
+    // would run past the source pitch falls back to dwords
+    const int k = tid & 7;
+    const u8* gp = sp + (size_t)__umul24(sy0 + (tid >> 3), spitch) + sxa + 16 * k;
+    unsigned* lp = s_src + __umul24(tid >> 3, RZ_SP / 4) + 4 * k;
+    const bool wide = sxa + 16 * k + 16 <= spitch;
+    if (4 * k < ndw)
+      for (int ty = tid >> 3; ty < nrow; ty += 32, gp += 32 * (size_t)spitch, lp += 32 * (RZ_SP / 4)) {
+        if (wide) { const uint4 v = *(const uint4*)gp; lp[0] = v.x; lp[1] = v.y; lp[2] = v.z; lp[3] = v.w; }
+        else
+          for (int j = 0; j < 4 && 4 * k + j < ndw; j++) lp[j] = *(const unsigned*)(gp + 4 * j);
+      }
   }
   __syncthreads();
   if (!live) return;
@@ -290,11 +297,13 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs A) {
   // ---- phase 0: pixel tile rows y0-4 .. y0+35, columns x0-4 .. x0+67 ----------------------------------------------------
   const bool interior = x0 >= 4 && x0 + 68 <= w && y0 >= 4 && y0 + FT_H + 4 <= h;
   if (interior) {
-    const int k = tid & 31;
-    if (k < FT_NG) {
-      const u8* gp = sp + (size_t)__umul24(y0 - 4 + (tid >> 5), pitch) + x0 - 4 + 4 * k;
-      unsigned* lp = s_px + __umul24(tid >> 5, FT_PD) + k;
-      for (int ty = tid >> 5; ty < FT_PR; ty += 8, gp += 8 * (size_t)pitch, lp += 8 * FT_PD) *lp = *(const unsigned*)gp;
+    // 72 bytes per row as four 16-byte loads and one 8-byte load (a lane address costs the same for 4 or 16 bytes)
+    if (tid < FT_PR * 5) {
+      const int ty = tid / 5, k = tid - ty * 5;
+      const u8* gp = sp + (size_t)__umul24(y0 - 4 + ty, pitch) + x0 - 4 + 16 * k;
+      unsigned* lp = s_px + __umul24(ty, FT_PD) + 4 * k;
+      if (k < 4) { const uint4 v = *(const uint4*)gp; lp[0] = v.x; lp[1] = v.y; lp[2] = v.z; lp[3] = v.w; }
+      else { const uint2 v = *(const uint2*)gp; lp[0] = v.x; lp[1] = v.y; }
     }
   } else {
     u8* sb = (u8*)s_px;
@@ -646,9 +655,13 @@ __global__ __launch_bounds__(256) void blur7_kernel(const u8* __restrict__ pyr, 
   // ---- stage 1: source tile rows y0-3 .. y0+BL_H+2, bytes x0-4 .. x0+67 ------------------------------------
   const bool interior = x0 >= 4 && x0 + 68 <= w && y0 >= 3 && y0 + BL_H + 3 <= h;
   if (interior) {
-    for (int i = tid; i < (BL_H + 6) * (BL_SP / 4); i += 256) {
-      int ty = i / (BL_SP / 4), k = i - ty * (BL_SP / 4);
-      s_src[i] = *(const unsigned*)(sp + (size_t)(y0 - 3 + ty) * pitch + x0 - 4 + 4 * k);
+    // 72 bytes per row as four 16-byte loads and one 8-byte load (a lane address costs the same for 4 or 16 bytes)
+    if (tid < (BL_H + 6) * 5) {
+      const int ty = tid / 5, k = tid - ty * 5;
+      const u8* gp = sp + (size_t)(y0 - 3 + ty) * pitch + x0 - 4 + 16 * k;
+      unsigned* lp = s_src + ty * (BL_SP / 4) + 4 * k;
+      if (k < 4) { const uint4 v = *(const uint4*)gp; lp[0] = v.x; lp[1] = v.y; lp[2] = v.z; lp[3] = v.w; }
+      else { const uint2 v = *(const uint2*)gp; lp[0] = v.x; lp[1] = v.y; }
     }
   } else {
     u8* sb = (u8*)s_src;
