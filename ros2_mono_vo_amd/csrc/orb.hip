@@ -295,23 +295,20 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs A) {
   if (tid == 0) { s_n = 0; s_n2 = 0; }
   if (tid < 2 * FT_H) s_rowmask[tid >> 1][tid & 1] = 0u;
   // ---- phase 0: pixel tile rows y0-4 .. y0+35, columns x0-4 .. x0+67 ----------------------------------------------------
-  const bool interior = x0 >= 4 && x0 + 68 <= w && y0 >= 4 && y0 + FT_H + 4 <= h;
-  if (interior) {
-    // 72 bytes per row as four 16-byte loads and one 8-byte load (a lane address costs the same for 4 or 16 bytes)
-    if (tid < FT_PR * 5) {
-      const int ty = tid / 5, k = tid - ty * 5;
-      const u8* gp = sp + (size_t)__umul24(y0 - 4 + ty, pitch) + x0 - 4 + 16 * k;
-      unsigned* lp = s_px + __umul24(ty, FT_PD) + 4 * k;
-      if (k < 4) { const uint4 v = *(const uint4*)gp; lp[0] = v.x; lp[1] = v.y; lp[2] = v.z; lp[3] = v.w; }
-      else { const uint2 v = *(const uint2*)gp; lp[0] = v.x; lp[1] = v.y; }
-    }
-  } else {
-    u8* sb = (u8*)s_px;
-    for (int i = tid; i < FT_PR * 72; i += 256) {
-      int ty = i / 72, tx = i - ty * 72;
-      int gx = min(max(x0 - 4 + tx, 0), w - 1), gy = min(max(y0 - 4 + ty, 0), h - 1);
-      sb[ty * FT_P + tx] = sp[(size_t)__umul24(gy, pitch) + gx];
-    }
+  // 72 bytes per row as four 16-byte loads and one 8-byte load (a lane address costs the same for 4 or 16 bytes).  Border
+  // tiles take the same path: rows are clamped into the image, the left-most tile starts at column 0 one dword further
+  // into the LDS row, and nothing is read past the row pitch.  Halo bytes outside the image then hold arbitrary data,
+  // which no needed score depends on: scores are computed for [lo, w - lo) x [lo, h - lo) with lo >= 3 = circle radius.
+  if (tid < FT_PR * 5) {
+    const int ty = tid / 5, k = tid - ty * 5;
+    const int gy = min(max(y0 - 4 + ty, 0), h - 1);
+    const int sh1 = x0 == 0 ? 1 : 0;
+    const int gx = x0 - 4 + 16 * k + 4 * sh1;
+    const u8* gp = sp + (size_t)__umul24(gy, pitch) + gx;
+    unsigned* lp = s_px + __umul24(ty, FT_PD) + 4 * k + sh1;
+    if (k < 4) { const uint4 v = *(const uint4*)gp; lp[0] = v.x; lp[1] = v.y; lp[2] = v.z; lp[3] = v.w; }
+    else if (gx + 8 <= pitch) { const uint2 v = *(const uint2*)gp; lp[0] = v.x; lp[1] = v.y; }
+    else { lp[0] = gx + 4 <= pitch ? *(const unsigned*)gp : 0u; lp[1] = 0u; }
   }
   for (int i = tid; i < FT_SR * FT_PD; i += 256) s_sc[i] = 0u;
   __syncthreads();
