@@ -650,15 +650,35 @@ __global__ __launch_bounds__(256) void blur7_kernel(const u8* __restrict__ pyr, 
   const int x0 = bx * BL_W, y0 = by * BL_H;
   const int tid = threadIdx.x;
   // ---- stage 1: source tile rows y0-3 .. y0+BL_H+2, bytes x0-4 .. x0+67 ------------------------------------
-  const bool interior = x0 >= 4 && x0 + 68 <= w && y0 >= 3 && y0 + BL_H + 3 <= h;
-  if (interior) {
-    // 72 bytes per row as four 16-byte loads and one 8-byte load (a lane address costs the same for 4 or 16 bytes)
+  // 72 bytes per row as four 16-byte loads and one 8-byte load (a lane address costs the same for 4 or 16 bytes).  Border
+  // tiles: rows by reflect-101; the left-most tile starts at column 0 one dword further into the LDS row; nothing is
+  // read past the row pitch; then the (at most three) reflected columns a stored output needs on either side are
+  // copied inside LDS.  Columns further out feed only outputs that are not stored.
+  const bool tiny = w < 8 || h < 8;
+  if (!tiny) {
     if (tid < (BL_H + 6) * 5) {
       const int ty = tid / 5, k = tid - ty * 5;
-      const u8* gp = sp + (size_t)(y0 - 3 + ty) * pitch + x0 - 4 + 16 * k;
-      unsigned* lp = s_src + ty * (BL_SP / 4) + 4 * k;
+      const int gy = d_reflect101(y0 - 3 + ty, h);
+      const int sh1 = x0 == 0 ? 1 : 0;
+      const int gx = x0 - 4 + 16 * k + 4 * sh1;
+      const u8* gp = sp + (size_t)gy * pitch + gx;
+      unsigned* lp = s_src + ty * (BL_SP / 4) + 4 * k + sh1;
       if (k < 4) { const uint4 v = *(const uint4*)gp; lp[0] = v.x; lp[1] = v.y; lp[2] = v.z; lp[3] = v.w; }
-      else { const uint2 v = *(const uint2*)gp; lp[0] = v.x; lp[1] = v.y; }
+      else if (sh1) { lp[0] = gx + 4 <= pitch ? *(const unsigned*)gp : 0u; }   // columns 64..67; the row has 18 dwords
+      else if (gx + 8 <= pitch) { const uint2 v = *(const uint2*)gp; lp[0] = v.x; lp[1] = v.y; }
+      else { lp[0] = gx + 4 <= pitch ? *(const unsigned*)gp : 0u; lp[1] = 0u; }
+    }
+    if (x0 == 0 || x0 + 67 > w) {   // block-uniform
+      __syncthreads();
+      if (tid < BL_H + 6) {
+        u8* rowb = (u8*)s_src + tid * BL_SP;
+        if (x0 == 0) { rowb[1] = rowb[7]; rowb[2] = rowb[6]; rowb[3] = rowb[5]; }   // x = -3, -2, -1 <- 3, 2, 1
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          const int x = w + j;                                     // <- w - 2 - j
+          if (x <= x0 + 67 && x >= x0) rowb[x - x0 + 4] = rowb[w - 2 - j - x0 + 4];
+        }
+      }
     }
   } else {
     u8* sb = (u8*)s_src;
