@@ -36,15 +36,36 @@ __global__ __launch_bounds__(256) void pyrdown_kernel(ImgSet src, ImgSet dst, Ti
   u8* dp = dst.slot(bz);
   const int dx0 = bx * PD_TW, dy0 = by * PD_TH, tid = threadIdx.x;
   const int sx0 = 2 * dx0 - 4, sy0 = 2 * dy0 - 2;   // tile origin (dword aligned in x)
-  const bool interior = sx0 >= 0 && sx0 + 136 <= src.w && sy0 >= 0 && sy0 + PD_SR <= src.h;
-  if (interior) {
-    // 136 bytes per row as eight 16-byte loads and one 8-byte load (a lane address costs the same for 4 or 16 bytes)
+  // 136 bytes per row as eight 16-byte loads and one 8-byte load (a lane address costs the same for 4 or 16 bytes).
+  // Border tiles: rows by reflect-101; the left-most tile starts at column 0 one dword further into the LDS row;
+  // nothing is read past the row pitch; then the two reflected columns the 5-tap filter needs on either side are
+  // copied inside LDS (outputs stop at 2 * dst.w - 1 <= src.w, so at most columns -2, -1 and w, w + 1).
+  const bool tiny = src.w < 8 || src.h < 8;
+  if (!tiny) {
+    const int sh1 = sx0 < 0 ? 1 : 0;
     for (int i = tid; i < PD_SR * 9; i += 256) {
       const int ty = __umul24(i, 7282) >> 16, k = i - ty * 9;   // i / 9 for i < 2^12
-      const u8* gp = sp + (size_t)__umul24(sy0 + ty, src.pitch) + sx0 + 16 * k;
-      unsigned* lp = s_src + ty * PD_SD + 4 * k;
-      if (k < 8) { const uint4 v = *(const uint4*)gp; lp[0] = v.x; lp[1] = v.y; lp[2] = v.z; lp[3] = v.w; }
-      else { const uint2 v = *(const uint2*)gp; lp[0] = v.x; lp[1] = v.y; }
+      const int gy = d_reflect101(sy0 + ty, src.h);
+      const int gx = sx0 + 16 * k + 4 * sh1;
+      const u8* gp = sp + (size_t)__umul24(gy, src.pitch) + gx;
+      unsigned* lp = s_src + ty * PD_SD + 4 * k + sh1;
+      if (gx + 16 <= src.pitch && k < 8) { const uint4 v = *(const uint4*)gp; lp[0] = v.x; lp[1] = v.y; lp[2] = v.z; lp[3] = v.w; }
+      else {
+        const int nd = k < 8 ? 4 : 2;
+        for (int j = 0; j < nd; j++) lp[j] = gx + 4 * j + 4 <= src.pitch ? *(const unsigned*)(gp + 4 * j) : 0u;
+      }
+    }
+    if (sx0 < 0 || sx0 + 136 > src.w) {   // block-uniform
+      __syncthreads();
+      if (tid < PD_SR) {
+        u8* rowb = (u8*)s_src + tid * (PD_SD * 4);
+        if (sx0 < 0) { rowb[2] = rowb[6]; rowb[3] = rowb[5]; }   // x = -2, -1 <- 2, 1
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const int x = src.w + j;                                // <- w - 2 - j
+          if (x < sx0 + 136 && x >= sx0) rowb[x - sx0] = rowb[src.w - 2 - j - sx0];
+        }
+      }
     }
   } else {
     u8* sb = (u8*)s_src;
