@@ -248,9 +248,9 @@ __device__ __forceinline__ void lk_accumulate(const unsigned* jt, int byte_off, 
   {                                                                                                                 \
     const unsigned sel = (unsigned)(k) | (0x0Cu << 8) | ((unsigned)((k) + 1) << 16) | (0x0Cu << 24);               \
     unsigned p0 = __builtin_amdgcn_perm(r0hi, r0lo, sel), p1 = __builtin_amdgcn_perm(r1hi, r1lo, sel);             \
-    int acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_short2, p0), w0, 0, false);                              \
+    int acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_short2, p0), w0, Iv[k], false);                          \
     acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_short2, p1), w1, acc, false);                                \
-    int diff = ((acc + (1 << 8)) >> 9) - Iv[k];                                                                     \
+    int diff = acc >> 9;   /* Iv[k] = 256 - 512 * I:  ((J + 256) >> 9) - I == (J + 256 - 512 * I) >> 9 exactly */  \
     if (ERR) { s1 += abs(diff); }                                                                                   \
     else { s1 += __mul24(diff, Ixv[k]); s2 += __mul24(diff, Iyv[k]); }                                              \
   }
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs A) {
           const unsigned p0 = __builtin_amdgcn_perm(r0hi, r0lo, sel), p1 = __builtin_amdgcn_perm(r1hi, r1lo, sel);
           int acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_short2, p0), w0, 0, false);
           acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_short2, p1), w1, acc, false);
-          Iv[i] = descale(acc, 14 - 5);
+          Iv[i] = 256 - (descale(acc, 14 - 5) << 9);   // kept as the start value of the iteration's accumulator (lk_accumulate)
         }
       }
       const unsigned* d0 = (const unsigned*)&S.dt[r * LK_DT + x0];
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs A) {
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 7; i++) { Iv[i] = 0; Ixv[i] = 0; Iyv[i] = 0; }
+      for (int i = 0; i < 7; i++) { Iv[i] = 256; Ixv[i] = 0; Iyv[i] = 0; }
     }
     // per lane: 7 * 4080^2 < 2^27
     long long sA11 = wave_sum_exact_bounded<4>(a11), sA12 = wave_sum_exact_bounded<4>(a12), sA22 = wave_sum_exact_bounded<4>(a22);
