@@ -29,8 +29,10 @@ struct ModelParams { CamK cam; };
 // ---------------------------------------------------------------------------------------------------
 struct HModel {
   static constexpr int MP = 4, MAXM = 1, MS = 9, PT1 = 2, PT2 = 2;
-  static constexpr int CH = 16, WS = 81 + 9 + 81;  // LtL, W, V
-  static constexpr bool WIDE = true;
+  // 32 hypotheses per round, every round in LDS (32 x 193 doubles = 49 KB): a 64-wide round with 48 workspaces in
+  // private memory took 2.85 ms against 0.8 ms for an LDS round, i.e. more per hypothesis
+  static constexpr int CH = 32, WS = 81 + 9 + 81;  // LtL, W, V
+  static constexpr bool WIDE = false;
   static constexpr int LMEDS_BELOW = 0;
 
   __device__ static bool check_subset(const float* ms1, const float* ms2) {
