@@ -76,6 +76,9 @@ __global__ __launch_bounds__(RS_T, RS_WAVES_PER_EU) void ransac_kernel(RansacArg
   __shared__ unsigned long long s_rng;
   __shared__ double s_minmed;
 
+  // one latency-bound wavefront per stream next to VALU-saturating image kernels: without priority it only gets a
+  // round-robin share of the SIMD's issue slots and a hard stream's chain (5 x the instructions) gates the step
+  __builtin_amdgcn_s_setprio(3);
   const int slot = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int count = min(max(A.n[slot], 0), A.cap);
   const float* m1 = A.m1 + (size_t)slot * A.stride1;
@@ -404,6 +407,7 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
   __shared__ double s_sh[160];  // broadcast area
   __shared__ double s_mat[2 * 144 + 16];  // lane-0 dense solves work in LDS, not in scratch (latency)
   __shared__ int s_flag[4];
+  __builtin_amdgcn_s_setprio(3);   // see ransac_kernel
   const int slot = blockIdx.x, tid = threadIdx.x;
   int* result = A.result + (size_t)slot * 8;
   double* pose = A.pose + (size_t)slot * 8;

@@ -31,7 +31,7 @@ struct HModel {
   static constexpr int MP = 4, MAXM = 1, MS = 9, PT1 = 2, PT2 = 2;
   // 32 hypotheses per round, every round in LDS (32 x 193 doubles = 49 KB): a 64-wide round with 48 workspaces in
   // private memory took 2.85 ms against 0.8 ms for an LDS round, i.e. more per hypothesis
-  static constexpr int CH = 32, WS = 81 + 9 + 81;  // LtL, W, V
+  static constexpr int CH = 16, WS = 81 + 9 + 81;  // LtL, W, V
   static constexpr bool WIDE = false;
   static constexpr int LMEDS_BELOW = 0;
 
@@ -687,7 +687,7 @@ struct PnPModel {
   // 24 hypotheses per round, every round in LDS (24 x 321 doubles = 61.6 KB): a round is latency bound, ~0.85 ms
   // whatever its width up to the LDS capacity, while a 64-wide round with 40 workspaces in private memory took 3.8 ms -
   // more per hypothesis than the LDS rounds, and coarser when the iteration bound shrinks mid-way
-  static constexpr int CH = 24, WS = 144 + 144 + 12;  // MtM -> Ut; M / the small solves' workspaces; singular values
+  static constexpr int CH = 16, WS = 144 + 144 + 12;  // MtM -> Ut; M / the small solves' workspaces; singular values
   static constexpr bool WIDE = false;
   static constexpr int LMEDS_BELOW = 0;
   __device__ static bool check_subset(const float*, const float*) { return true; }
