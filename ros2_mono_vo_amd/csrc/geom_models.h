@@ -29,8 +29,9 @@ struct ModelParams { CamK cam; };
 // ---------------------------------------------------------------------------------------------------
 struct HModel {
   static constexpr int MP = 4, MAXM = 1, MS = 9, PT1 = 2, PT2 = 2;
-  // 32 hypotheses per round, every round in LDS (32 x 193 doubles = 49 KB): a 64-wide round with 48 workspaces in
-  // private memory took 2.85 ms against 0.8 ms for an LDS round, i.e. more per hypothesis
+  // 16 hypotheses per round, every round in LDS (16 x 193 doubles = 25 KB): a 64-wide round with 48 workspaces in
+  // private memory took 2.85 ms against 0.8 ms for an LDS round, i.e. more per hypothesis; wider LDS rounds (24, 32)
+  // made the workgroup wait for LDS beside the image kernels
   static constexpr int CH = 16, WS = 81 + 9 + 81;  // LtL, W, V
   static constexpr bool WIDE = false;
   static constexpr int LMEDS_BELOW = 0;
@@ -684,9 +685,11 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
 
 struct PnPModel {
   static constexpr int MP = 5, MAXM = 1, MS = 6, PT1 = 3, PT2 = 2;
-  // 24 hypotheses per round, every round in LDS (24 x 321 doubles = 61.6 KB): a round is latency bound, ~0.85 ms
-  // whatever its width up to the LDS capacity, while a 64-wide round with 40 workspaces in private memory took 3.8 ms -
-  // more per hypothesis than the LDS rounds, and coarser when the iteration bound shrinks mid-way
+  // Every round is 16 wide with the workspaces in LDS (16 x 321 doubles = 41 KB): a round is latency bound, ~0.85 ms
+  // whatever its width, while a 64-wide round with 48 workspaces in private memory took 3.8 ms - more per hypothesis
+  // than the LDS rounds, and coarser when the iteration bound shrinks mid-way.  24 lanes (62 KB) fit as well and need
+  // fewer rounds, but a 62 KB workgroup waits for LDS beside the image kernels' workgroups once 512 streams are
+  // resident (the launch took twice as long); 12 lanes need too many rounds.
   static constexpr int CH = 16, WS = 144 + 144 + 12;  // MtM -> Ut; M / the small solves' workspaces; singular values
   static constexpr bool WIDE = false;
   static constexpr int LMEDS_BELOW = 0;
