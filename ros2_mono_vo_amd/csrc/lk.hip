@@ -230,10 +230,11 @@ __device__ __forceinline__ int lk_load_tile(unsigned* lds, const u8* __restrict_
 }
 
 // One lane's 7 pixels of (bilinear J - I) against (Ix, Iy) or |.|: two unaligned 8-byte row spans are read
-// as 3 dwords each and re-aligned with v_alignbyte; v_perm builds (p_k, p_k+1) 16-bit pairs and two
-// v_dot2c_i32_i16 evaluate the 4-tap fixed-point bilinear sum exactly.
+// as 3 dwords each and re-aligned with v_alignbyte.  v_perm builds the eight VERTICAL pairs V_k = (row0[k], row1[k])
+// as 16-bit lanes - neighbouring pixels share them - and two v_dot2c_i32_i16 per pixel, V_k . (w00, w10) +
+// V_k+1 . (w01, w11), evaluate the 4-tap fixed-point bilinear sum exactly.  Wa = w00 | w10 << 16, Wb = w01 | w11 << 16.
 template <bool ERR>
-__device__ __forceinline__ void lk_accumulate(const unsigned* jt, int byte_off, bool active, unsigned W0, unsigned W1, const int* Iv,
+__device__ __forceinline__ void lk_accumulate(const unsigned* jt, int byte_off, bool active, unsigned Wa, unsigned Wb, const int* Iv,
                                               const int* Ixv, const int* Iyv, int& s1, int& s2) {
   s1 = 0; s2 = 0;
   if (!active) return;
@@ -243,13 +244,18 @@ __device__ __forceinline__ void lk_accumulate(const unsigned* jt, int byte_off, 
   unsigned b0 = q[LK_JP / 4], b1 = q[LK_JP / 4 + 1], b2 = q[LK_JP / 4 + 2];
   unsigned r0lo = __builtin_amdgcn_alignbyte(a1, a0, sh), r0hi = __builtin_amdgcn_alignbyte(a2, a1, sh);
   unsigned r1lo = __builtin_amdgcn_alignbyte(b1, b0, sh), r1hi = __builtin_amdgcn_alignbyte(b2, b1, sh);
-  const lk_short2 w0 = __builtin_bit_cast(lk_short2, W0), w1 = __builtin_bit_cast(lk_short2, W1);
+  const lk_short2 wa = __builtin_bit_cast(lk_short2, Wa), wb = __builtin_bit_cast(lk_short2, Wb);
+  lk_short2 V[8];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const unsigned sel = (unsigned)k | (0x0Cu << 8) | ((unsigned)(4 + k) << 16) | (0x0Cu << 24);   // (src1 byte k, src0 byte k)
+    V[k] = __builtin_bit_cast(lk_short2, __builtin_amdgcn_perm(r1lo, r0lo, sel));
+    V[4 + k] = __builtin_bit_cast(lk_short2, __builtin_amdgcn_perm(r1hi, r0hi, sel));
+  }
 #define LK_PIX(k)                                                                                                   \
   {                                                                                                                 \
-    const unsigned sel = (unsigned)(k) | (0x0Cu << 8) | ((unsigned)((k) + 1) << 16) | (0x0Cu << 24);               \
-    unsigned p0 = __builtin_amdgcn_perm(r0hi, r0lo, sel), p1 = __builtin_amdgcn_perm(r1hi, r1lo, sel);             \
-    int acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_short2, p0), w0, Iv[k], false);                          \
-    acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_short2, p1), w1, acc, false);                                \
+    int acc = __builtin_amdgcn_sdot2(V[k], wa, Iv[k], false);                                                       \
+    acc = __builtin_amdgcn_sdot2(V[(k) + 1], wb, acc, false);                                                       \
     int diff = acc >> 9;   /* Iv[k] = 256 - 512 * I:  ((J + 256) >> 9) - I == (J + 256 - 512 * I) >> 9 exactly */  \
     if (ERR) { s1 += abs(diff); }                                                                                   \
     else { s1 += __mul24(diff, Ixv[k]); s2 += __mul24(diff, Iyv[k]); }                                              \
@@ -418,8 +424,8 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs A) {
       }
       lk_weights(nx - inx, ny - iny, w00, w01, w10, w11);
       int s1, s2;
-      lk_accumulate<false>(S.jt, (r + ddy) * LK_JP + x0 + ddx + shJ, active, (unsigned)w00 | ((unsigned)w01 << 16),
-                           (unsigned)w10 | ((unsigned)w11 << 16), Iv, Ixv, Iyv, s1, s2);
+      lk_accumulate<false>(S.jt, (r + ddy) * LK_JP + x0 + ddx + shJ, active, (unsigned)w00 | ((unsigned)w10 << 16),
+                           (unsigned)w01 | ((unsigned)w11 << 16), Iv, Ixv, Iyv, s1, s2);
       long long sb1 = wave_sum_exact_bounded<3>(s1), sb2 = wave_sum_exact_bounded<3>(s2);  // per lane: 7 * 8160 * 4080 < 2^28
       float b1 = (float)(sb1 * A.cn) * FLT_SCALE;
       float b2 = (float)(sb2 * A.cn) * FLT_SCALE;
@@ -452,8 +458,8 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs A) {
         }
         lk_weights(ex - inx, ey - iny, w00, w01, w10, w11);
         int s1, s2;
-        lk_accumulate<true>(S.jt, (r + ddy) * LK_JP + x0 + ddx + shJ, active, (unsigned)w00 | ((unsigned)w01 << 16),
-                            (unsigned)w10 | ((unsigned)w11 << 16), Iv, Ixv, Iyv, s1, s2);
+        lk_accumulate<true>(S.jt, (r + ddy) * LK_JP + x0 + ddx + shJ, active, (unsigned)w00 | ((unsigned)w10 << 16),
+                            (unsigned)w01 | ((unsigned)w11 << 16), Iv, Ixv, Iyv, s1, s2);
         long long se = (long long)wave_sum_i32_dpp(s1);  // 64 * 7 * 8160 fits 32 bits
         float errval = (float)(se * A.cn);
         errv = errval * 1.f / (float)(32 * LK_WIN * A.cn * LK_WIN);
