@@ -343,15 +343,16 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs A) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // ---- template in registers + exact A sums ---------------------------------------------------------
-    // Same machinery as the iteration: (p_k, p_k+1) 16-bit pairs by v_perm, the 4-tap fixed-point sums by two
-    // v_dot2c_i32_i16; the derivative field is interleaved (dx, dy), so its pairs come from two adjacent entries.
+    // Same machinery as the iteration: vertical 16-bit pairs (row r, row r + 1) by v_perm, shared by neighbouring
+    // pixels, and the 4-tap fixed-point sums by two v_dot2c_i32_i16; the derivative field is interleaved (dx, dy), so
+    // the low / high halves of two vertically adjacent entries give the dx / dy pairs.
     int w00, w01, w10, w11;
     lk_weights(px - ipx, py - ipy, w00, w01, w10, w11);
     int Iv[7], Ixv[7], Iyv[7];
     int a11 = 0, a12 = 0, a22 = 0;
     if (active) {
-      const lk_short2 w0 = __builtin_bit_cast(lk_short2, (unsigned)w00 | ((unsigned)w01 << 16));
-      const lk_short2 w1 = __builtin_bit_cast(lk_short2, (unsigned)w10 | ((unsigned)w11 << 16));
+      const lk_short2 wa = __builtin_bit_cast(lk_short2, (unsigned)w00 | ((unsigned)w10 << 16));
+      const lk_short2 wb = __builtin_bit_cast(lk_short2, (unsigned)w01 | ((unsigned)w11 << 16));
       {
         const int bo = (r + 1) * LK_IP + x0 + 1 + shI, sh = bo & 3;
         const unsigned* q = S.it + (bo >> 2);
@@ -359,29 +360,35 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs A) {
         const unsigned b0 = q[LK_IP / 4], b1 = q[LK_IP / 4 + 1], b2 = q[LK_IP / 4 + 2];
         const unsigned r0lo = __builtin_amdgcn_alignbyte(a1, a0, sh), r0hi = __builtin_amdgcn_alignbyte(a2, a1, sh);
         const unsigned r1lo = __builtin_amdgcn_alignbyte(b1, b0, sh), r1hi = __builtin_amdgcn_alignbyte(b2, b1, sh);
+        lk_short2 V[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const unsigned sel = (unsigned)k | (0x0Cu << 8) | ((unsigned)(4 + k) << 16) | (0x0Cu << 24);
+          V[k] = __builtin_bit_cast(lk_short2, __builtin_amdgcn_perm(r1lo, r0lo, sel));
+          V[4 + k] = __builtin_bit_cast(lk_short2, __builtin_amdgcn_perm(r1hi, r0hi, sel));
+        }
 #pragma unroll
         for (int i = 0; i < 7; i++) {
-          const unsigned sel = (unsigned)i | (0x0Cu << 8) | ((unsigned)(i + 1) << 16) | (0x0Cu << 24);
-          const unsigned p0 = __builtin_amdgcn_perm(r0hi, r0lo, sel), p1 = __builtin_amdgcn_perm(r1hi, r1lo, sel);
-          int acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_short2, p0), w0, 0, false);
-          acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_short2, p1), w1, acc, false);
+          int acc = __builtin_amdgcn_sdot2(V[i], wa, 0, false);
+          acc = __builtin_amdgcn_sdot2(V[i + 1], wb, acc, false);
           Iv[i] = 256 - (descale(acc, 14 - 5) << 9);   // kept as the start value of the iteration's accumulator (lk_accumulate)
         }
       }
       const unsigned* d0 = (const unsigned*)&S.dt[r * LK_DT + x0];
       const unsigned* d1 = d0 + LK_DT;
-      unsigned e0[8], e1[8];
+      lk_short2 XV[8], YV[8];   // (dx, dx below), (dy, dy below) at positions x0 .. x0 + 7
 #pragma unroll
-      for (int i = 0; i < 8; i++) { e0[i] = d0[i]; e1[i] = d1[i]; }
+      for (int i = 0; i < 8; i++) {
+        const unsigned e0 = d0[i], e1 = d1[i];
+        XV[i] = __builtin_bit_cast(lk_short2, __builtin_amdgcn_perm(e1, e0, 0x05040100u));
+        YV[i] = __builtin_bit_cast(lk_short2, __builtin_amdgcn_perm(e1, e0, 0x07060302u));
+      }
 #pragma unroll
       for (int i = 0; i < 7; i++) {
-        // (dx_i, dx_i+1) = low halves, (dy_i, dy_i+1) = high halves of two neighbouring (dx, dy) entries
-        const unsigned x0p = __builtin_amdgcn_perm(e0[i + 1], e0[i], 0x05040100u), y0p = __builtin_amdgcn_perm(e0[i + 1], e0[i], 0x07060302u);
-        const unsigned x1p = __builtin_amdgcn_perm(e1[i + 1], e1[i], 0x05040100u), y1p = __builtin_amdgcn_perm(e1[i + 1], e1[i], 0x07060302u);
-        int ix = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_short2, x0p), w0, 0, false);
-        ix = descale(__builtin_amdgcn_sdot2(__builtin_bit_cast(lk_short2, x1p), w1, ix, false), 14);
-        int iy = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_short2, y0p), w0, 0, false);
-        iy = descale(__builtin_amdgcn_sdot2(__builtin_bit_cast(lk_short2, y1p), w1, iy, false), 14);
+        int ix = __builtin_amdgcn_sdot2(XV[i], wa, 0, false);
+        ix = descale(__builtin_amdgcn_sdot2(XV[i + 1], wb, ix, false), 14);
+        int iy = __builtin_amdgcn_sdot2(YV[i], wa, 0, false);
+        iy = descale(__builtin_amdgcn_sdot2(YV[i + 1], wb, iy, false), 14);
         Ixv[i] = ix; Iyv[i] = iy;
         a11 += __mul24(ix, ix); a12 += __mul24(ix, iy); a22 += __mul24(iy, iy);
       }
