@@ -320,24 +320,40 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs A) {
         col[q][2] = __builtin_amdgcn_alignbyte(d3, d2, ph);
         col[q][3] = d3 >> (8 * ph);
       }
-      int Sv[13], Dv[13];
+      // packed 16-bit arithmetic, two columns per register: S <= 4080 and |D| <= 255, |dx|, |dy| <= 4080
+      typedef unsigned short lk_us2 __attribute__((ext_vector_type(2)));
+      lk_us2 Sp[7], Dp[7];   // columns (2j, 2j+1); column 13 is padding and only reaches the unused output 11
 #pragma unroll
-      for (int c = 0; c < 13; c++) {
-        const int t = (int)((col[0][c >> 2] >> (8 * (c & 3))) & 0xFFu), m = (int)((col[1][c >> 2] >> (8 * (c & 3))) & 0xFFu),
-                  bt = (int)((col[2][c >> 2] >> (8 * (c & 3))) & 0xFFu);
-        Sv[c] = (t + bt) * 3 + m * 10;
-        Dv[c] = bt - t;
+      for (int j = 0; j < 7; j++) {
+        const unsigned selp = (j & 1) ? 0x0c030c02u : 0x0c010c00u;   // bytes (2, 3) / (0, 1) of the dword as two u16
+        const lk_us2 t = __builtin_bit_cast(lk_us2, __builtin_amdgcn_perm(0u, col[0][j >> 1], selp));
+        const lk_us2 m = __builtin_bit_cast(lk_us2, __builtin_amdgcn_perm(0u, col[1][j >> 1], selp));
+        const lk_us2 b = __builtin_bit_cast(lk_us2, __builtin_amdgcn_perm(0u, col[2][j >> 1], selp));
+        const lk_us2 three = {3, 3}, ten = {10, 10};
+        Sp[j] = (t + b) * three + m * ten;
+        Dp[j] = b - t;   // two's complement in 16 bits
       }
-      const int gy = ipy + ty;
+      const int gy = ipy + ty, gx0 = ipx + tx0;
       const bool row_ok = (unsigned)gy < (unsigned)lv.h;
-      short2* dst = &S.dt[ty * LK_DT + tx0];
+      const bool all_ok = row_ok && gx0 >= 0 && gx0 + 10 < lv.w;
+      const bool fast = __all(all_ok) != 0;   // nearly always: the window lies inside the image
+      unsigned* dst = (unsigned*)&S.dt[ty * LK_DT + tx0];
 #pragma unroll
-      for (int k = 0; k < 11; k++) {
-        const int gx = ipx + tx0 + k;
-        int dx = Sv[k + 2] - Sv[k];
-        int dy = (Dv[k] + Dv[k + 2]) * 3 + Dv[k + 1] * 10;
-        const bool ok = row_ok && (unsigned)gx < (unsigned)lv.w;
-        dst[k] = ok ? make_short2((short)dx, (short)dy) : make_short2(0, 0);
+      for (int j = 0; j < 6; j++) {
+        const lk_us2 three = {3, 3}, ten = {10, 10};
+        const lk_us2 dxp = Sp[j + 1] - Sp[j];                                    // dx of outputs 2j, 2j+1
+        const lk_us2 mid = __builtin_bit_cast(lk_us2, __builtin_amdgcn_alignbyte(__builtin_bit_cast(unsigned, Dp[j + 1]),
+                                                                                  __builtin_bit_cast(unsigned, Dp[j]), 2));
+        const lk_us2 dyp = (Dp[j] + Dp[j + 1]) * three + mid * ten;              // dy of outputs 2j, 2j+1
+        const unsigned X = __builtin_bit_cast(unsigned, dxp), Y = __builtin_bit_cast(unsigned, dyp);
+        unsigned e0 = __builtin_amdgcn_perm(Y, X, 0x05040100u);                  // (dx, dy) of output 2j
+        unsigned e1 = __builtin_amdgcn_perm(Y, X, 0x07060302u);                  // (dx, dy) of output 2j+1
+        if (!fast) {
+          if (!(row_ok && (unsigned)(gx0 + 2 * j) < (unsigned)lv.w)) e0 = 0u;
+          if (!(row_ok && (unsigned)(gx0 + 2 * j + 1) < (unsigned)lv.w)) e1 = 0u;
+        }
+        dst[2 * j] = e0;
+        if (j < 5) dst[2 * j + 1] = e1;   // output 11 does not exist
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
