@@ -312,30 +312,32 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs A) {
   }
   for (int i = tid; i < FT_SR * FT_PD; i += 256) s_sc[i] = 0u;
   __syncthreads();
-  // ---- phase 1: pre-test, 4 pixels per item; item = (score row sy, group g), image y = y0-1+sy, x = x0-4+4g+j ----------
+  // ---- phase 1: pre-test.  Scores are needed on rows y0-1 .. y0+32, columns x0-1 .. x0+64 (the tile plus the NMS ring),
+  // clipped to [lo, w-lo) x [lo, h-lo).  The 32 x 64 core goes as 512 items of 4 pixels from aligned dwords (two full
+  // passes), the 196 ring pixels one per lane; tiles whose ring lies inside the band skip every clipping test. --------
   {
     const ft_s2 t1 = {(short)(A.threshold + 1), (short)(A.threshold + 1)};
-    // columns of this tile that need a score: [x0-1, x0+64] clipped to [lo, w-lo)
-    const int cx_lo = max(x0 - 1, lo), cx_hi = min(x0 + FT_W + 1, w - lo);  // [cx_lo, cx_hi)
-    for (int it0 = 0; it0 < FT_SR * FT_NG; it0 += 256) {
-      const int it = it0 + tid;
-      unsigned cmask = 0;  // bit j: pixel j of the group is a candidate
-      int sy = 0, g = 0;
-      if (it < FT_SR * FT_NG) {
-        sy = it / FT_NG; g = it - sy * FT_NG;
-        const int gy = y0 - 1 + sy, gx = x0 - 4 + 4 * g;
-        if (gy >= lo && gy < h - lo && gx + 3 >= cx_lo && gx < cx_hi) {
-          const unsigned* c = s_px + __umul24(sy + 3, FT_PD) + g;
-          const unsigned Dl = c[-1], Dc = c[0], Dr = c[1], Du = c[-3 * FT_PD], Dd = c[3 * FT_PD];
-          const unsigned P4 = __builtin_amdgcn_alignbyte(Dr, Dc, 3);    // x + 3
-          const unsigned P12 = __builtin_amdgcn_alignbyte(Dc, Dl, 1);   // x - 3
-          unsigned s01 = ft_pretest2(ft_lo(Dc), ft_lo(Dd), ft_lo(Du), ft_lo(P4), ft_lo(P12), t1);
-          unsigned s23 = ft_pretest2(ft_hi(Dc), ft_hi(Dd), ft_hi(Du), ft_hi(P4), ft_hi(P12), t1);
-          cmask = (~s01 >> 15 & 1u) | (~s01 >> 30 & 2u) | (~s23 >> 13 & 4u) | (~s23 >> 28 & 8u);
-          // clip to the needed columns
+    const bool inner = x0 - 1 >= lo && x0 + FT_W + 1 <= w - lo && y0 - 1 >= lo && y0 + FT_H + 1 <= h - lo;  // block-uniform
+    const unsigned long long below = (1ull << lane) - 1;
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+      const int it = pass * 256 + tid;
+      const int r = it >> 4, gi = it & 15;
+      const int sy = r + 1, g = gi + 1;                 // score-tile row, dword group of the pixel tile
+      const int gy = y0 + r, gx = x0 + 4 * gi;
+      unsigned cmask = 0;                               // bit j: pixel j of the group is a candidate
+      if (inner || (gy >= lo && gy < h - lo && gx + 3 >= lo && gx < w - lo)) {
+        const unsigned* c = s_px + __umul24(sy + 3, FT_PD) + g;
+        const unsigned Dl = c[-1], Dc = c[0], Dr = c[1], Du = c[-3 * FT_PD], Dd = c[3 * FT_PD];
+        const unsigned P4 = __builtin_amdgcn_alignbyte(Dr, Dc, 3);    // x + 3
+        const unsigned P12 = __builtin_amdgcn_alignbyte(Dc, Dl, 1);   // x - 3
+        unsigned s01 = ft_pretest2(ft_lo(Dc), ft_lo(Dd), ft_lo(Du), ft_lo(P4), ft_lo(P12), t1);
+        unsigned s23 = ft_pretest2(ft_hi(Dc), ft_hi(Dd), ft_hi(Du), ft_hi(P4), ft_hi(P12), t1);
+        cmask = (~s01 >> 15 & 1u) | (~s01 >> 30 & 2u) | (~s23 >> 13 & 4u) | (~s23 >> 28 & 8u);
+        if (!inner) {
 #pragma unroll
           for (int j = 0; j < 4; j++)
-            if (gx + j < cx_lo || gx + j >= cx_hi) cmask &= ~(1u << j);
+            if (gx + j < lo || gx + j >= w - lo) cmask &= ~(1u << j);
         }
       }
       // one LDS atomic per wave and pass; the order of the list does not matter
@@ -344,12 +346,32 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs A) {
       int base = 0;
       if (lane == 0 && (n0 + n1 + n2 + n3)) base = atomicAdd(&s_n, n0 + n1 + n2 + n3);
       base = __shfl(base, 0, 64);
-      const unsigned long long below = (1ull << lane) - 1;
       const unsigned code = (unsigned)(sy << 7) | (unsigned)(4 * g);
       if (cmask & 1u) s_list[base + __popcll(m0 & below)] = (unsigned short)(code);
       if (cmask & 2u) s_list[base + n0 + __popcll(m1 & below)] = (unsigned short)(code + 1);
       if (cmask & 4u) s_list[base + n0 + n1 + __popcll(m2 & below)] = (unsigned short)(code + 2);
       if (cmask & 8u) s_list[base + n0 + n1 + n2 + __popcll(m3 & below)] = (unsigned short)(code + 3);
+    }
+    {
+      // the ring: rows sy = 0 and FT_SR-1 (66 columns each), columns c = 3 and 68 of rows 1 .. FT_H
+      int sy, c;
+      if (tid < 66) { sy = 0; c = 3 + tid; }
+      else if (tid < 132) { sy = FT_SR - 1; c = 3 + (tid - 66); }
+      else if (tid < 132 + FT_H) { sy = 1 + (tid - 132); c = 3; }
+      else { sy = 1 + ((tid - 132 - FT_H) & (FT_H - 1)); c = FT_W + 4; }
+      const int gy = y0 - 1 + sy, gx = x0 - 4 + c;
+      bool cand = false;
+      if (tid < 132 + 2 * FT_H && (inner || (gy >= lo && gy < h - lo && gx >= lo && gx < w - lo))) {
+        const u8* q = (const u8*)s_px + __umul24(sy + 3, FT_P) + c;
+        const int v = q[0], p0 = q[3 * FT_P], p8 = q[-3 * FT_P], p4 = q[3], p12 = q[-3];
+        const int M = min(max(p0, p8), max(p4, p12)), m = max(min(p0, p8), min(p4, p12));
+        cand = M - v > A.threshold || v - m > A.threshold;
+      }
+      const unsigned long long mb = __ballot(cand);
+      int base = 0;
+      if (lane == 0 && mb) base = atomicAdd(&s_n, __popcll(mb));
+      base = __shfl(base, 0, 64);
+      if (cand) s_list[base + __popcll(mb & below)] = (unsigned short)((sy << 7) | c);
     }
   }
   __syncthreads();
