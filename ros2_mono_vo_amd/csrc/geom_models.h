@@ -515,8 +515,8 @@ __device__ GL_NOINLINE double ep_compute_R_and_t(EpnpState& e, const double* ut,
 }
 
 // solvePnP(SOLVEPNP_EPNP) for 5 float correspondences -> rvec, tvec
-// ws: 300 doubles.  [288,300) singular values; [0,144) MtM, rotated in place into Ut by the SVD; [144,288) first M (2n x 12), then the SVD's V,
-// then the workspaces of the three small least-squares solves.
+// ws: 288 doubles.  [0,144) MtM, rotated in place into Ut by the SVD; [144,276) first M (2n x 12 = 120), then dv (72) + L (60) and,
+// over the dead dv, the workspaces of the three small least-squares solves; [276,288) singular values.
 __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const CamK& cam, double rvec[3], double tvec[3], double* ws) {
   const int n = EP_N;
   EpnpState e;
@@ -593,7 +593,7 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
     // ut == mtm.  Lanes whose workspace is in LDS take the unrolled 12 x 12 routine; the private-memory lanes of a wide
     // RANSAC round take the general one (same arithmetic)
     // cvSVD(MtM, D, Ut, 0): only the left vectors are read, V is not formed (no value of Ut depends on it)
-    if (gl_is_lds(ws)) gl_jacobi_svd12_lds<false>((gl_lds_double*)mtm, (gl_lds_double*)(ws + 288), nullptr);
+    if (gl_is_lds(ws)) gl_jacobi_svd12_lds<false>((gl_lds_double*)mtm, (gl_lds_double*)(ws + 276), nullptr);
     else gl_jacobi_svd(mtm, 12, d, nullptr, 12, 12, 12, true);
   }
   // dv (4 x 6 x 3) and L_6x10 live in the workspace (the V block is free after the SVD) and their loops stay rolled:
@@ -685,12 +685,12 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
 
 struct PnPModel {
   static constexpr int MP = 5, MAXM = 1, MS = 6, PT1 = 3, PT2 = 2;
-  // Every round is 16 wide with the workspaces in LDS (16 x 321 doubles = 41 KB): a round is latency bound, ~0.85 ms
+  // Every round is 20 wide with the workspaces in LDS (20 x 289 doubles = 46 KB): a round is latency bound, ~0.85 ms
   // whatever its width, while a 64-wide round with 48 workspaces in private memory took 3.8 ms - more per hypothesis
-  // than the LDS rounds, and coarser when the iteration bound shrinks mid-way.  24 lanes (62 KB) fit as well and need
-  // fewer rounds, but a 62 KB workgroup waits for LDS beside the image kernels' workgroups once 512 streams are
-  // resident (the launch took twice as long); 12 lanes need too many rounds.
-  static constexpr int CH = 16, WS = 144 + 144 + 12;  // MtM -> Ut; M / the small solves' workspaces; singular values
+  // than the LDS rounds, and coarser when the iteration bound shrinks mid-way.  24 lanes of the earlier 300-double
+  // workspace (62 KB) needed as few rounds, but a 62 KB workgroup waits for LDS beside the image kernels' workgroups
+  // once 512 streams are resident (the launch took twice as long); 12 lanes need too many rounds.
+  static constexpr int CH = 20, WS = 144 + 132 + 12;  // MtM -> Ut; M (120), then dv + L (132) / the small solves' workspaces; singular values
   static constexpr bool WIDE = false;
   static constexpr int LMEDS_BELOW = 0;
   __device__ static bool check_subset(const float*, const float*) { return true; }
