@@ -544,8 +544,8 @@ int lk_track_device(mvo_ctx* ctx, int prev_set, int cur_set, const LkLevels& L, 
 
 extern "C" int mvo_pyrdown(mvo_ctx* ctx, const uint8_t* src, int w, int h, int stride, uint8_t* dst,
                            int dstride) {
-  if (!ctx || !src || !dst || w < 2 || h < 2 || w > ctx->maxw || h > ctx->maxh) return MVO_E_ARG;
-  LkLevels L = lk_levels(w, h, 1, 1);
+  if (!ctx || !src || !dst || w < 1 || h < 1 || w > ctx->maxw || h > ctx->maxh) return MVO_E_ARG;
+  LkLevels L = lk_levels(w, h, 0, 1);   // win 0: no early stop, a 1 x 1 level is a valid cv::pyrDown result
   ImgSet s = lk_imgset(ctx, 0, L, 0), d = lk_imgset(ctx, 0, L, 1);
   int rc = upload_gray(ctx, src, w, h, stride, 1, s.base, s.pitch, 0);
   if (rc) return rc;

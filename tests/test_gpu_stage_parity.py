@@ -30,6 +30,11 @@ def test_pyrdown_bitexact(ctx720, frames720):
         img = o
     odd = frames720[0][:333, :517]
     assert np.array_equal(ctx720.pyrdown(odd), O.pyrdown(odd))
+    # border tiles of every kind (one tile wide / high, right edge inside the last 16-byte group) and the per-byte path
+    # of images under 8 pixels
+    for h, w in ((33, 64), (64, 130), (17, 259), (200, 61), (9, 8), (5, 7), (3, 9), (2, 2), (2, 3), (3, 2), (1, 5), (4, 1), (1, 1)):
+        small = np.ascontiguousarray(frames720[1][100:100 + h, 300:300 + w])
+        assert np.array_equal(ctx720.pyrdown(small), O.pyrdown(small)), (h, w)
 
 
 def test_fast_corner_indices_bitexact(ctx720, frames720, frames480):
