@@ -156,14 +156,15 @@ __global__ __launch_bounds__(256) void resize_exact_kernel(const u8* __restrict_
     const u8* r0 = (const u8*)s_src + __umul24((ye[q] & 0xFFFFu) - sy0, RZ_SP) - sxa;
     const u8* r1 = r0 + RZ_SP;
     unsigned out = 0;
+    const int nvalid = min(4, dw - x);   // 4 except in the last lanes of the right-most tile
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      if (x + j < dw) {
+      if (j < nvalid) {
         const unsigned ox = xes[j] & 0xFFFFu, cx1 = xes[j] >> 16, cx0 = 256u - cx1;
         unsigned h0 = __umul24(cx0, r0[ox]) + __umul24(cx1, r0[ox + 1]);   // < 2^16
         unsigned h1 = __umul24(cx0, r1[ox]) + __umul24(cx1, r1[ox + 1]);
-        unsigned v = __umul24(h0, cy0) + __umul24(h1, cy1);
-        out |= min(255u, (v + 32768u) >> 16) << (8 * j);
+        unsigned v = __umul24(h0, cy0) + __umul24(h1, cy1);               // weights sum to 2^16: v <= 255 * 2^16
+        out |= ((v + 32768u) >> 16) << (8 * j);                           // <= 255, no clamp needed
       }
     }
     *(unsigned*)(dp + (size_t)__umul24(y, dpitch) + x) = out;  // x % 4 == 0 and pitch % 64 == 0: the padding columns take zeros
