@@ -128,6 +128,20 @@ def test_orb_and_lk_bitexact_1080_c4():
         assert len(gk) == len(ok) and np.array_equal(gk["x"], ok["x"]) and np.array_equal(gk["y"], ok["y"]) and np.array_equal(gd, od)
 
 
+def test_orb_lk_match_kitti_shape():
+    """BASELINE config C1 geometry (KITTI odometry: 1241 x 376, 1000 features): odd width, so every right-edge tile is
+    partial and the row pitch ends inside a 16-byte group."""
+    from ros2_mono_vo_amd import Context
+    fr = synth.gen_stream(1241, 376, 0x5EED0001, 2)
+    with Context(max_width=1241, max_height=376, nfeatures=1000, max_points=4096) as ctx:
+        _check_orb(ctx, fr[0], 1000)
+        _check_orb(ctx, fr[1], 1000)
+        k0, d0 = O.orb_detect_and_compute(fr[0], 1000)
+        _, d1 = O.orb_detect_and_compute(fr[1], 1000)
+        _check_lk(ctx, fr[0], fr[1], np.stack([k0["x"], k0["y"]], 1))
+        assert np.array_equal(ctx.match_knn2_ratio(d0, d1, 0.7), O.match_knn2_ratio(d0, d1, 0.7))
+
+
 def test_orb_bitexact_wide_frame():
     """Frames wider than 2048 px take the one-row-per-wavefront emit path (more than 32 segments per row)."""
     from ros2_mono_vo_amd import Context
