@@ -18,9 +18,9 @@ def planar_landmarks(K, z=10.0):
     return f
 
 
-@pytest.mark.parametrize("B", [1, 3])
-def test_batch_step_matches_oracle_flow(B):
-    W, H, NF, STEPS = 640, 480, 1000, 4
+@pytest.mark.parametrize("B,W,H", [(1, 640, 480), (3, 640, 480), (2, 1241, 376)])   # the last one: KITTI geometry, odd width
+def test_batch_step_matches_oracle_flow(B, W, H):
+    NF, STEPS = 1000, 4
     K = synth.default_K(W, H)
     streams = [synth.gen_stream(W, H, 0x5EED0100 + s, STEPS + 1) for s in range(B)]
     with Context(max_width=W, max_height=H, batch=B, nfeatures=NF, max_points=4096, ring_frames=STEPS + 1) as ctx:
