@@ -720,12 +720,7 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
 // triangulation (one point per lane) and recoverPose
 // ---------------------------------------------------------------------------------------------------
 // cv::triangulatePoints for one correspondence: null vector of the 4x4 DLT matrix = last row of Vt.  The 4x4 Jacobi SVD
-// runs in registers (gl_jacobi_svd_fixed); a rank-deficient system takes the general routine instead.
-__device__ GL_NOINLINE void gm_triangulate_general(const double* A, double X[4]) {
-  double w[4], vt[16], ta[16], tv[16];
-  gl_svd_compute(A, 4, 4, w, nullptr, vt, false, ta, tv);
-  for (int k = 0; k < 4; k++) X[k] = vt[12 + k];
-}
+// runs in registers (gl_jacobi_svd_fixed, V only), rank-deficient systems included.
 __device__ inline void gm_triangulate_one(const double* P1, const double* P2, double x1, double y1, double x2, double y2, double X[4]) {
   double A[16], At[16], W[4], Vt[16];
 #pragma unroll
@@ -739,12 +734,10 @@ __device__ inline void gm_triangulate_one(const double* P1, const double* P2, do
   for (int i = 0; i < 4; i++)
 #pragma unroll
     for (int j = 0; j < 4; j++) At[j * 4 + i] = A[i * 4 + j];
-  if (gl_jacobi_svd_fixed<4, 4>(At, W, Vt)) {
+  // only Vt is read: no left-vector completion, also when the system is rank deficient (zero baseline)
+  gl_jacobi_svd_fixed<4, 4, false>(At, W, Vt);
 #pragma unroll
-    for (int k = 0; k < 4; k++) X[k] = Vt[12 + k];
-  } else {
-    gm_triangulate_general(A, X);
-  }
+  for (int k = 0; k < 4; k++) X[k] = Vt[12 + k];
 }
 
 struct Proj2 { double P1[12], P2[12]; };

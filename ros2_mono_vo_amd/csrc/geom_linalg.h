@@ -339,7 +339,10 @@ __device__ inline void gl_jacobi_svd12_lds(gl_lds_double* At, gl_lds_double* W, 
 // gl_jacobi_svd (every loop unrolled, the data-dependent row swaps of the final sort written as predicated swaps over
 // static indices).  Only the main path: when a singular value is <= DBL_MIN the reference completes the basis with a
 // seeded Gram-Schmidt; that case returns false and the caller re-runs the general routine.
-template <int M, int N>
+// NEED_U = false: the caller reads W and Vt only.  The completion branch rewrites rows of At (the left vectors) and
+// nothing else, so it is skipped and the call always succeeds - rank-deficient systems (e.g. triangulation with a zero
+// baseline) stay on the register path.
+template <int M, int N, bool NEED_U = true>
 __device__ __forceinline__ bool gl_jacobi_svd_fixed(double (&At)[N * M], double (&W)[N], double (&Vt)[N * N]) {
   const double minval = DBL_MIN, eps = DBL_EPSILON * 10;
   const int max_iter = M > 30 ? M : 30;
@@ -416,6 +419,7 @@ __device__ __forceinline__ bool gl_jacobi_svd_fixed(double (&At)[N * M], double 
         for (int k = 0; k < N; k++) gl_swap(Vt[i * N + k], Vt[q * N + k]);
       }
   }
+  if (!NEED_U) return true;
   bool ok = true;
 #pragma unroll
   for (int i = 0; i < N; i++) ok = ok && W[i] > minval;

@@ -142,6 +142,12 @@ def test_triangulate_bitexact(ctx720):
     g = ctx720.triangulate(P1, P2, sc["p1"], sc["p2"])
     o, _ = O.triangulate(P1, P2, sc["p1"], sc["p2"])
     assert np.array_equal(g, o)
+    # rank-deficient systems (zero baseline: both cameras identical; and the same pixel in both views): OpenCV's SVD
+    # completes the LEFT vectors there, the null vector comes from V and is unaffected - same bits as the oracle
+    for Pa, Pb, a, b2 in ((P1, P1, sc["p1"], sc["p1"]), (P1, P1, sc["p1"], sc["p2"]), (P2, P2, sc["p2"][:300], sc["p2"][:300])):
+        g = ctx720.triangulate(Pa, Pb, a, b2)
+        o, _ = O.triangulate(Pa, Pb, a, b2)
+        assert np.array_equal(g, o, equal_nan=True)
 
 
 def test_recover_pose(ctx720):
