@@ -359,30 +359,30 @@ __global__ __launch_bounds__(1024) void mask_to_indices_kernel(const u8* __restr
   if (threadIdx.x == 0) result[(size_t)slot * 8 + 5] = s_base;
 }
 
-// One wavefront per stream: the kernel needs ~500 VGPRs for its 78 double accumulators, and a 4-wave workgroup of
-// that size per stream took every SIMD of the chip for itself (ORB's kernels on the main stream stalled behind it).
-#define PR_T 64
+// Block size of the refine.  Throughput mode (many streams resident) runs one wavefront per stream: the kernel is
+// register heavy, and a 4-wave workgroup per stream took every SIMD of the chip for itself while ORB's kernels on the
+// main stream stalled behind it.  With few streams nothing competes and the chain LK -> RANSAC -> refine IS the step
+// latency, so the sums over the inliers run four wavefronts wide (mvo_ctx decides by the batch size).
 #ifndef PR_WAVES_PER_EU
 #define PR_WAVES_PER_EU 2
 #endif
-#define PR_NW (PR_T / 64)
 // deterministic block-wide sum of `K` doubles per thread: butterfly inside each wave (every lane ends with the same
-// bits), then the wave partials through LDS in a fixed order.  s_red must hold PR_NW*K doubles.
-template <int K>
+// bits), then the wave partials through LDS in a fixed order.  s_red must hold NW*K doubles.
+template <int K, int NW>
 __device__ inline void block_sum(double* v, double* s_red, double* out /* [K], valid in all threads */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int k = 0; k < K; k++) {
     double x = v[k];
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
-    if (PR_NW == 1) out[k] = x;
+    if (NW == 1) out[k] = x;
     else if (lane == 0) s_red[wave * K + k] = x;
   }
-  if (PR_NW == 1) return;
+  if (NW == 1) return;
   __syncthreads();
   for (int k = 0; k < K; k++) {
     double t = s_red[k];
-    for (int w = 1; w < PR_NW; w++) t += s_red[w * K + k];
+    for (int w = 1; w < NW; w++) t += s_red[w * K + k];
     out[k] = t;
   }
   __syncthreads();
@@ -402,7 +402,9 @@ struct PnpRefineArgs {
 
 // One workgroup per stream.  Sums over the inlier set are block reductions in a fixed order (the oracle
 // sums sequentially, so R,t agree to rounding, not bit for bit); the small dense solves run on lane 0.
+template <int PR_T>
 __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRefineArgs A) {
+  constexpr int PR_NW = PR_T / 64;
   __shared__ double s_red[PR_NW * 78];
   __shared__ double s_sh[160];  // broadcast area
   __shared__ double s_mat[2 * 144 + 16];  // lane-0 dense solves work in LDS, not in scratch (latency)
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
   {
     double v[3] = {0, 0, 0};
     for (int i = tid; i < count; i += PR_T) { double M[3]; ptM(i, M); v[0] += M[0]; v[1] += M[1]; v[2] += M[2]; }
-    block_sum<3>(v, s_red, Mc);
+    block_sum<3, PR_NW>(v, s_red, Mc);
     for (int j = 0; j < 3; j++) Mc[j] /= count;
   }
   double MM[9];
@@ -449,7 +451,7 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
       v[0] += d0 * d0; v[1] += d0 * d1; v[2] += d0 * d2; v[3] += d1 * d1; v[4] += d1 * d2; v[5] += d2 * d2;
     }
     double o[6];
-    block_sum<6>(v, s_red, o);
+    block_sum<6, PR_NW>(v, s_red, o);
     MM[0] = o[0]; MM[1] = MM[3] = o[1]; MM[2] = MM[6] = o[2]; MM[4] = o[3]; MM[5] = MM[7] = o[4]; MM[8] = o[5];
   }
   // lane 0: planarity test (3x3 SVD), broadcast Vt and the flag
@@ -482,7 +484,7 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
     {
       double v[4] = {0, 0, 0, 0};
       for (int i = tid; i < count; i += PR_T) { double X, Y, x, y; mxy(i, X, Y); mnorm(i, x, y); v[0] += x; v[1] += y; v[2] += X; v[3] += Y; }
-      block_sum<4>(v, s_red, c4);
+      block_sum<4, PR_NW>(v, s_red, c4);
       for (int k = 0; k < 4; k++) c4[k] /= count;
     }
     double s4[4];
@@ -492,7 +494,7 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
         double X, Y, x, y; mxy(i, X, Y); mnorm(i, x, y);
         v[0] += fabs(x - c4[0]); v[1] += fabs(y - c4[1]); v[2] += fabs(X - c4[2]); v[3] += fabs(Y - c4[3]);
       }
-      block_sum<4>(v, s_red, s4);
+      block_sum<4, PR_NW>(v, s_red, s4);
     }
     bool degenerate = fabs(s4[0]) < DBL_EPSILON || fabs(s4[1]) < DBL_EPSILON || fabs(s4[2]) < DBL_EPSILON || fabs(s4[3]) < DBL_EPSILON;
     double smx = count / s4[0], smy = count / s4[1], sMx = count / s4[2], sMy = count / s4[3];
@@ -509,7 +511,7 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
           for (int j = 0; j < 9; j++)
             for (int k = j; k < 9; k++) acc[q++] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
         }
-      block_sum<45>(acc, s_red, LtL);
+      block_sum<45, PR_NW>(acc, s_red, LtL);
     }
     if (tid == 0) {
       double R[9];
@@ -583,7 +585,7 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
       for (int a = 0; a < 12; a++)
         for (int b = a; b < 12; b++) acc[q++] += l0[a] * l0[b] + l1[a] * l1[b];
     }
-    block_sum<78>(acc, s_red, LL);
+    block_sum<78, PR_NW>(acc, s_red, LL);
     if (tid == 0) {
       double* L = s_mat;
       double* LV = s_mat + 144;
@@ -665,12 +667,12 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
     }
     double o[28];
     if (withJ) {
-      block_sum<28>(v, s_red, o);
+      block_sum<28, PR_NW>(v, s_red, o);
       for (int k = 0; k < 21; k++) JtJ[k] = o[k];
       for (int k = 0; k < 6; k++) JtErr[k] = o[21 + k];
       curErr2 = o[27];
     } else {
-      block_sum<1>(v + 27, s_red, o);
+      block_sum<1, PR_NW>(v + 27, s_red, o);
       curErr2 = o[0];
     }
   };
@@ -873,7 +875,9 @@ int geom_pnp(mvo_ctx* ctx, int nslots, const float* obj, const float* img, const
   hipLaunchKernelGGL(mask_to_indices_kernel, dim3(nslots), dim3(1024), 0, st, mask, ctx->maxpts, d_n, inl, ctx->maxpts, result);
   PnpRefineArgs R;
   R.obj = obj; R.img = img; R.stride_pts = ctx->maxpts; R.inl = inl; R.result = result; R.model = model; R.n = d_n; R.pose = pose; R.cam = P.cam;
-  hipLaunchKernelGGL(pnp_refine_kernel, dim3(nslots), dim3(PR_T), 0, st, R);
+  const bool wide = ctx->refine_waves ? ctx->refine_waves == 4 : nslots <= 64;
+  if (wide) hipLaunchKernelGGL(pnp_refine_kernel<256>, dim3(nslots), dim3(256), 0, st, R);
+  else hipLaunchKernelGGL(pnp_refine_kernel<64>, dim3(nslots), dim3(64), 0, st, R);
   return MVO_OK;
 }
 

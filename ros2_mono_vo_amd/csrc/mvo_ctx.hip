@@ -1,5 +1,6 @@
 // csrc/mvo_ctx.hip — context lifetime, configuration defaults, image upload.
 #include "mvo_internal.h"
+#include <cstdlib>
 
 #include <cmath>
 
@@ -97,6 +98,7 @@ extern "C" int mvo_create(const mvo_config* cfg, mvo_ctx** out) {
   ctx->maxw = cfg->max_width;
   ctx->maxh = cfg->max_height;
   ctx->maxpts = cfg->max_points;
+  if (const char* e = getenv("MVO_PNP_REFINE_WAVES")) ctx->refine_waves = atoi(e) == 4 ? 4 : (atoi(e) == 1 ? 1 : 0);
   *out = ctx;
   if (cfg->device >= 0) MVO_HIP(hipSetDevice(cfg->device));
   if (cfg->hip_stream) {

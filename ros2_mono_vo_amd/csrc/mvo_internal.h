@@ -41,6 +41,7 @@ struct mvo_ctx {
   void set_error(const std::string& s) { err = s; }
 
   int B = 1;       // slots
+  int refine_waves = 0;  // PnP refine block: 0 = by batch size, 1 / 4 wavefronts forced (MVO_PNP_REFINE_WAVES, tests)
   int maxw = 0, maxh = 0, maxpts = 0;
 
   // ---- LK: two pyramid sets (ping-pong "prev"/"cur") --------------------------------------------

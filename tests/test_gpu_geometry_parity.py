@@ -77,6 +77,22 @@ def test_pnp_ransac(ctx720, P, planar):
     assert np.abs(O.rodrigues(r) - Rgt).max() < 2e-3 and np.abs(t - sc["t"]).max() < 5e-2
 
 
+@pytest.mark.parametrize("waves", [1, 4])
+def test_pnp_refine_block_sizes(waves, monkeypatch):
+    """The LM refine runs one wavefront per stream when many streams are resident and four when few are (latency);
+    MVO_PNP_REFINE_WAVES forces either: same inliers, poses within the same tolerance of the oracle."""
+    from ros2_mono_vo_amd import Context
+    monkeypatch.setenv("MVO_PNP_REFINE_WAVES", str(waves))
+    with Context(max_width=1280, max_height=720, max_points=8192) as ctx:
+        for P, planar in ((1000, False), (1000, True)):
+            sc = scene(P, planar)
+            ok, r, t, idx = ctx.solve_pnp_ransac(sc["X"], sc["p2"], sc["K"])
+            rc, orv, otv, oidx, st = O.solve_pnp_ransac(sc["X"], sc["p2"], sc["K"])
+            assert ok and rc == 1 and np.array_equal(idx, oidx)
+            assert np.abs(r - orv).max() <= 1e-9 * max(1.0, np.abs(orv).max())
+            assert np.abs(t - otv).max() <= 1e-9 * max(1.0, np.abs(otv).max())
+
+
 def test_fundamental_lmeds_branch(ctx720):
     """findFundamentalMat(FM_RANSAC) with 8..14 points runs LMedS (fundam.cpp): 300 fixed iterations, least median.
     With 14 points the median (element 7 of the sorted errors) is a non-sample point's residual and the result is
