@@ -341,17 +341,27 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs A) {
             if (gx + j < lo || gx + j >= w - lo) cmask &= ~(1u << j);
         }
       }
-      // one LDS atomic per wave and pass; the order of the list does not matter
-      const unsigned long long m0 = __ballot(cmask & 1u), m1 = __ballot(cmask & 2u), m2 = __ballot(cmask & 4u), m3 = __ballot(cmask & 8u);
-      const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
+      // candidates of the wave -> list: per-lane counts, inclusive wave prefix by DPP adds (rows of 16, then the two
+      // row broadcasts), one LDS atomic per wave and pass; the order of the list does not matter
+      const int nc = __popc(cmask);
+      int inc = nc;
+      inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xF, 0xF, true);    // row_shr:1
+      inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xF, 0xF, true);    // row_shr:2
+      inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xF, 0xF, true);    // row_shr:4
+      inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xF, 0xF, true);    // row_shr:8
+      inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+      inc += __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
+      const int total = __builtin_amdgcn_readlane(inc, 63);
+      if (total == 0) continue;                                               // wave-uniform
       int base = 0;
-      if (lane == 0 && (n0 + n1 + n2 + n3)) base = atomicAdd(&s_n, n0 + n1 + n2 + n3);
-      base = __shfl(base, 0, 64);
+      if (lane == 0) base = atomicAdd(&s_n, total);
+      base = __builtin_amdgcn_readfirstlane(base);
+      int pos = base + inc - nc;
       const unsigned code = (unsigned)(sy << 7) | (unsigned)(4 * g);
-      if (cmask & 1u) s_list[base + __popcll(m0 & below)] = (unsigned short)(code);
-      if (cmask & 2u) s_list[base + n0 + __popcll(m1 & below)] = (unsigned short)(code + 1);
-      if (cmask & 4u) s_list[base + n0 + n1 + __popcll(m2 & below)] = (unsigned short)(code + 2);
-      if (cmask & 8u) s_list[base + n0 + n1 + n2 + __popcll(m3 & below)] = (unsigned short)(code + 3);
+      if (cmask & 1u) s_list[pos++] = (unsigned short)(code);
+      if (cmask & 2u) s_list[pos++] = (unsigned short)(code + 1);
+      if (cmask & 4u) s_list[pos++] = (unsigned short)(code + 2);
+      if (cmask & 8u) s_list[pos] = (unsigned short)(code + 3);
     }
     {
       // the ring: rows sy = 0 and FT_SR-1 (66 columns each), columns c = 3 and 68 of rows 1 .. FT_H
