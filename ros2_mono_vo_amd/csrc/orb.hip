@@ -202,15 +202,22 @@ __device__ __forceinline__ void fast_ring(const u8* c, int (&d)[25]) {
   d[15] = v - c[3 * FT_P - 1];
 }
 
-// FAST-9: an arc of 9 contiguous circle pixels all darker than v - t or all brighter than v + t
+// FAST-9: an arc of 9 contiguous circle pixels all darker than v - t or all brighter than v + t.  The two 16-bit
+// masks are gathered sign bit by sign bit: p_k < v - t  <=>  (p_k - (v - t)) < 0, p_k > v + t  <=>  ((v + t) - p_k) < 0,
+// and v_alignbit_b32(acc, x, 31) = acc << 1 | sign(x) appends one bit per instruction (k = 15 first, so pixel k ends
+// at bit k) - no compare / select pairs.
 __device__ __forceinline__ bool fast_is_corner(const u8* c, int t) {
-  int d[25];
-  fast_ring(c, d);
-  unsigned mdark = 0, mbright = 0;  // dark: p < v - t  <=> d > t ; bright: p > v + t <=> d < -t
+  const int v = c[0];
+  const int lo = v - t, hi = v + t;
+  // circle offsets (dx,dy) k=0..15 as in fast_score.cpp makeOffsets(16)
+  const int p[16] = {c[3 * FT_P + 0],  c[3 * FT_P + 1],  c[2 * FT_P + 2],  c[1 * FT_P + 3], c[3],  c[-1 * FT_P + 3], c[-2 * FT_P + 2],
+                     c[-3 * FT_P + 1], c[-3 * FT_P + 0], c[-3 * FT_P - 1], c[-2 * FT_P - 2], c[-1 * FT_P - 3], c[-3], c[1 * FT_P - 3],
+                     c[2 * FT_P - 2],  c[3 * FT_P - 1]};
+  unsigned mdark = 0, mbright = 0;
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    mdark |= (unsigned)(d[k] > t) << k;
-    mbright |= (unsigned)(d[k] < -t) << k;
+  for (int k = 15; k >= 0; k--) {
+    mdark = __builtin_amdgcn_alignbit(mdark, (unsigned)(p[k] - lo), 31);
+    mbright = __builtin_amdgcn_alignbit(mbright, (unsigned)(hi - p[k]), 31);
   }
   return has9(mdark) || has9(mbright);
 }
