@@ -13,6 +13,7 @@
 #ifndef MVO_H_
 #define MVO_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -176,6 +177,19 @@ int mvo_triangulate(mvo_ctx* ctx, const double P1[12], const double P2[12], cons
 #define MVO_STAGE_TRIANG 32u    /* triangulate the matches                   (src/tracker.cpp:208-209) */
 #define MVO_STAGE_ALL 63u
 
+/* Tracker state of a slot (mvo_batch_track): TrackerState of include/mono_vo/tracker.hpp:20-24 after the INITIALIZING
+ * hand-over, plus ABORTED for the case the reference does not survive: solvePnPRansac finds no model, rvec stays empty
+ * and cv::Rodrigues (src/tracker.cpp:315) throws out of image_callback.  LOST and ABORTED are terminal. */
+#define MVO_TRACK_TRACKING 0
+#define MVO_TRACK_LOST 1
+#define MVO_TRACK_ABORTED 2
+/* What a slot did on this frame (mvo_step_result.flags). */
+#define MVO_STEP_LOST_NOW 1u     /* fewer than min_tracked_points survivors: LOST, no pose     (src/tracker.cpp:292-296) */
+#define MVO_STEP_POSE 2u         /* Tracker::update returned a pose (rvec / tvec are T_cw)      (src/tracker.cpp:315-316) */
+#define MVO_STEP_KF_CHECKED 4u   /* should_add_keyframe was true: H / F RANSAC ran             (src/tracker.cpp:319-320) */
+#define MVO_STEP_KEYFRAME 8u     /* has_parallax was true: add_new_keyframe ran                (src/tracker.cpp:321-322) */
+#define MVO_STEP_ABORTED_NOW 16u /* solvePnPRansac found no model (see MVO_TRACK_ABORTED) */
+
 typedef struct mvo_step_result {
   int n_prev;         /* points fed to LK */
   int n_tracked;      /* status && err < tracking_error_thresh */
@@ -183,6 +197,11 @@ typedef struct mvo_step_result {
   double rvec[3], tvec[3];
   int score_h, score_f;
   int n_keypoints, n_matches, n_triangulated;
+  /* mvo_batch_track only (mvo_batch_step leaves them 0) */
+  int state;          /* MVO_TRACK_* after this frame */
+  unsigned flags;     /* MVO_STEP_* */
+  int tracking_count; /* tracking_count_from_keyframe_ after this frame */
+  int n_tracks;       /* observations with landmarks carried into the next frame (prev_frame_) */
 } mvo_step_result;
 
 int mvo_batch_preload_frame(mvo_ctx* ctx, int slot, int frame_idx, const uint8_t* img, int w, int h, int stride,
@@ -195,6 +214,39 @@ int mvo_batch_get_tracks(mvo_ctx* ctx, int slot, float* pts /* cap x 2 */, int c
 int mvo_batch_set_landmarks(mvo_ctx* ctx, int slot, const float* xyz /* n x 3 */, int n);
 int mvo_batch_set_intrinsics(mvo_ctx* ctx, const double K[9], const double d[5]);
 int mvo_batch_step(mvo_ctx* ctx, int frame_idx, unsigned stages, mvo_step_result* out /* [batch] */);
+
+/* ---- frame-batch mode as B x Tracker::update (src/tracker.cpp:274-333), device driven ----------------------------------
+ * Every slot carries its own tracker state on the device (state, tracking_count_from_keyframe_, last key-frame, tracks)
+ * and takes its own branch per frame: LOST below min_tracked_points (:292-296), should_add_keyframe (:118-136) from the
+ * slot's PnP pose, has_parallax (:237-268) from its H / F scores, add_new_keyframe (:182-235) only for the slots that
+ * pass - run over a compacted device-resident slot list.  No host wait inside a step: launches are sized for the worst
+ * case and read the real counts on the device, so a step can be enqueued asynchronously and several contexts interleave
+ * on one GPU.  Seed with mvo_batch_seed + mvo_batch_set_landmarks (the Initializer's hand-over, src/mono_vo.cpp:102-105).
+ *   mvo_batch_track_async  enqueue the step on ring frame `frame_idx`; returns at once
+ *   mvo_batch_track_poll   1 when the enqueued step has finished, 0 while it runs
+ *   mvo_batch_track_wait   block until it has finished, copy the per-slot results to out[batch] (may be NULL);
+ *                          MVO_E_CAPACITY if a device-side capacity was exceeded (results clamped)
+ *   mvo_batch_track        both
+ *   mvo_batch_set_policy   0: the reference's key-frame policy (default); 1: key-frame branch on every tracked frame
+ *                          (worst-case load for benchmarking; LOST / ABORTED handling unchanged)
+ *   mvo_batch_get_state    MVO_TRACK_* and tracking_count_from_keyframe_ of every slot (blocks) */
+int mvo_batch_track_async(mvo_ctx* ctx, int frame_idx);
+int mvo_batch_track_poll(mvo_ctx* ctx);
+int mvo_batch_track_wait(mvo_ctx* ctx, mvo_step_result* out /* [batch] */);
+int mvo_batch_track(mvo_ctx* ctx, int frame_idx, mvo_step_result* out /* [batch] */);
+int mvo_batch_set_policy(mvo_ctx* ctx, int policy);
+int mvo_batch_get_state(mvo_ctx* ctx, int* state /* [batch] */, int* tracking_count /* [batch] */);
+
+/* ---- asynchronous ingest (src/mono_vo.cpp:92-100: the image the callback hands to the tracker) ---------------------------
+ * mvo_batch_upload_async copies all `batch` mono8 frames of ring entry `frame_idx` (images `slot_stride` bytes apart, rows
+ * `stride` bytes apart) host -> device on a dedicated upload stream and returns at once; the step that uses the entry
+ * waits for the copy on the device, and the copy waits for the step that last read the entry.  With a ring of >= 2
+ * entries frame k+1 uploads while step k computes.  The host buffer must stay valid until the step that consumes it has
+ * been enqueued and its wait / poll has returned; pinned memory (mvo_host_alloc, or hipHostRegister'd memory) is what
+ * makes the copy asynchronous - pageable memory works but serialises. */
+int mvo_batch_upload_async(mvo_ctx* ctx, int frame_idx, const uint8_t* frames, int w, int h, int stride, size_t slot_stride);
+int mvo_host_alloc(size_t bytes, void** out);
+int mvo_host_free(void* p);
 
 /* Stage timers: HIP events recorded on the context's stream around each kernel group.
  * Names: "lk_pyramid", "lk_track", "orb_detect", "orb_describe", "match", "pnp", "ransac_h", "ransac_f", ... */

@@ -52,6 +52,8 @@ ABI_SYMBOLS = [
     "mvo_find_essential_ransac", "mvo_recover_pose", "mvo_triangulate",
     "mvo_batch_preload_frame", "mvo_batch_seed", "mvo_batch_get_tracks", "mvo_batch_set_landmarks",
     "mvo_batch_set_intrinsics", "mvo_batch_step", "mvo_profile_enable", "mvo_profile_read", "mvo_profile_reset",
+    "mvo_batch_track_async", "mvo_batch_track_poll", "mvo_batch_track_wait", "mvo_batch_track", "mvo_batch_set_policy",
+    "mvo_batch_get_state", "mvo_batch_upload_async", "mvo_host_alloc", "mvo_host_free",
 ]
 
 
@@ -59,10 +61,13 @@ class StepResult(C.Structure):
     """Mirror of `mvo_step_result` (include/mvo.h)."""
     _fields_ = [("n_prev", C.c_int), ("n_tracked", C.c_int), ("pnp_ok", C.c_int), ("n_pnp_inliers", C.c_int),
                 ("rvec", C.c_double * 3), ("tvec", C.c_double * 3), ("score_h", C.c_int), ("score_f", C.c_int),
-                ("n_keypoints", C.c_int), ("n_matches", C.c_int), ("n_triangulated", C.c_int)]
+                ("n_keypoints", C.c_int), ("n_matches", C.c_int), ("n_triangulated", C.c_int),
+                ("state", C.c_int), ("flags", C.c_uint), ("tracking_count", C.c_int), ("n_tracks", C.c_int)]
 
 
 STAGE_LK, STAGE_PNP, STAGE_HF, STAGE_ORB, STAGE_MATCH, STAGE_TRIANG, STAGE_ALL = 1, 2, 4, 8, 16, 32, 63
+TRACK_TRACKING, TRACK_LOST, TRACK_ABORTED = 0, 1, 2
+STEP_LOST_NOW, STEP_POSE, STEP_KF_CHECKED, STEP_KEYFRAME, STEP_ABORTED_NOW = 1, 2, 4, 8, 16
 
 _lib = None
 
@@ -91,6 +96,18 @@ def lib():
         L.mvo_destroy.argtypes = [C.c_void_p]
         L.mvo_destroy.restype = None
         L.mvo_sync.argtypes = [C.c_void_p]
+        L.mvo_batch_upload_async.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t]
+        L.mvo_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+        L.mvo_host_free.argtypes = [C.c_void_p]
+        for f in ("mvo_batch_track_async", "mvo_batch_track_poll", "mvo_batch_track_wait", "mvo_batch_track",
+                  "mvo_batch_set_policy", "mvo_batch_get_state"):
+            getattr(L, f).restype = C.c_int
+        L.mvo_batch_track_async.argtypes = [C.c_void_p, C.c_int]
+        L.mvo_batch_track_poll.argtypes = [C.c_void_p]
+        L.mvo_batch_track_wait.argtypes = [C.c_void_p, C.c_void_p]
+        L.mvo_batch_track.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.mvo_batch_set_policy.argtypes = [C.c_void_p, C.c_int]
+        L.mvo_batch_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 

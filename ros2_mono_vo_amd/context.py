@@ -164,6 +164,54 @@ class Context:
         self._check(self._L.mvo_batch_step(self._h, int(frame_idx), C.c_uint(stages), res))
         return res
 
+    # -- frame-batch mode as B x Tracker::update (device driven, asynchronous) ---------------------------------
+    def batch_track_async(self, frame_idx):
+        self._check(self._L.mvo_batch_track_async(self._h, int(frame_idx)))
+
+    def batch_track_poll(self):
+        return bool(self._L.mvo_batch_track_poll(self._h))
+
+    def batch_track_wait(self):
+        res = (_lib.StepResult * int(self.cfg.batch))()
+        self._check(self._L.mvo_batch_track_wait(self._h, res))
+        return res
+
+    def batch_track(self, frame_idx):
+        res = (_lib.StepResult * int(self.cfg.batch))()
+        self._check(self._L.mvo_batch_track(self._h, int(frame_idx), res))
+        return res
+
+    def batch_set_policy(self, policy):
+        self._check(self._L.mvo_batch_set_policy(self._h, int(policy)))
+
+    def batch_get_state(self):
+        st = np.zeros(int(self.cfg.batch), np.int32)
+        cnt = np.zeros(int(self.cfg.batch), np.int32)
+        self._check(self._L.mvo_batch_get_state(self._h, ptr(st), ptr(cnt)))
+        return st, cnt
+
+    def batch_upload_async(self, frame_idx, frames_ptr, w, h, stride, slot_stride):
+        """frames_ptr: host address of `batch` mono8 images (pinned memory for a truly asynchronous copy)."""
+        self._check(self._L.mvo_batch_upload_async(self._h, int(frame_idx), C.c_void_p(int(frames_ptr)), int(w), int(h), int(stride),
+                                                   C.c_size_t(int(slot_stride))))
+
+    def host_alloc(self, nbytes):
+        """Pinned host buffer as a uint8 numpy array (freed by host_free or with the process)."""
+        p = C.c_void_p()
+        rc = self._L.mvo_host_alloc(C.c_size_t(int(nbytes)), C.byref(p))
+        if rc != 0:
+            raise MvoError(rc, "mvo_host_alloc")
+        buf = (C.c_uint8 * int(nbytes)).from_address(p.value)
+        a = np.frombuffer(buf, np.uint8)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[a.ctypes.data] = p.value
+        return a
+
+    def host_free(self, arr):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p is not None:
+            self._L.mvo_host_free(C.c_void_p(p))
+
     # -- stage timers ------------------------------------------------------------------------------------
     def profile_enable(self, on=True):
         self._check(self._L.mvo_profile_enable(self._h, 1 if on else 0))

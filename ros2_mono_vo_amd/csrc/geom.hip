@@ -897,12 +897,15 @@ struct TriBatchArgs {
   int cap;
   float* X3;   // [B][cap][3]
   u8* valid;   // [B][cap]
+  const int* list;   // optional device list of slots (blockIdx.y indexes it), *nlist entries
+  const int* nlist;
 };
 
 __global__ __launch_bounds__(256) void triangulate_matches_kernel(TriBatchArgs A) {
   __shared__ double s_P[2][12];
   __shared__ double s_T[2][12];
-  const int slot = blockIdx.y;
+  if (A.list && (int)blockIdx.y >= *A.nlist) return;   // block-uniform
+  const int slot = A.list ? A.list[blockIdx.y] : blockIdx.y;
   const int n = min(max(A.n_matches[slot], 0), A.cap);
   if (blockIdx.x * 256 >= n) return;
   bool pose_ok = true;
@@ -940,9 +943,10 @@ __global__ __launch_bounds__(256) void triangulate_matches_kernel(TriBatchArgs A
 
 int geom_triangulate_matches(mvo_ctx* ctx, int nslots, int max_matches, const mvo_match* matches, const int* n_matches,
                              const float* kf_xy, const float* cur_xy, const double* kf_pose, const double* cur_pose,
-                             const int* pnp_result, const double K[9], float* X3, u8* valid) {
+                             const int* pnp_result, const double K[9], float* X3, u8* valid, const int* d_list, const int* d_nlist) {
   if (max_matches <= 0) return MVO_OK;
   TriBatchArgs A;
+  A.list = d_list; A.nlist = d_nlist;
   A.matches = matches; A.n_matches = n_matches; A.kf_xy = kf_xy; A.cur_xy = cur_xy; A.kf_pose = kf_pose; A.cur_pose = cur_pose;
   A.pnp_result = pnp_result; A.cam = CamK{K[0], K[4], K[2], K[5]}; A.cap = ctx->maxpts; A.X3 = X3; A.valid = valid;
   dim3 grid((max_matches + 255) / 256, nslots);

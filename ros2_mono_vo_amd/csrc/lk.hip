@@ -134,7 +134,16 @@ struct LkArgs {
   int max_count;
   double eps2;
   double min_eig;
+  // device-driven launch (frame-batch tracker): the points of all slots form one dense work list,
+  // work_slot[w] = slot of item w, pt_base[slot] = first item of the slot, pt_base[nslots] = item count; persistent
+  // wavefronts claim LK_CHUNK items at a time from work_ctr (zeroed before the launch).  Null: one wavefront per
+  // (blockIdx.x * 4 + wave, blockIdx.y) with the host-sized grid.
+  const int* work_slot;
+  const int* pt_base;
+  int* work_ctr;
+  int nslots;
 };
+#define LK_CHUNK 4
 
 #define LK_WIN 21
 #define LK_IT 24          // I tile edge (WIN + 1 bilinear + 2 Scharr halo)
@@ -264,13 +273,7 @@ __device__ __forceinline__ void lk_accumulate(const unsigned* jt, int byte_off, 
 #undef LK_PIX
 }
 
-__global__ __launch_bounds__(256) void lk_track_kernel(LkArgs A) {
-  __shared__ LkWaveLds lds[4];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int slot = blockIdx.y;
-  const int p = blockIdx.x * 4 + wave;
-  if (p >= min(A.npts[slot], A.maxpts)) return;  // wave-uniform
-  LkWaveLds& S = lds[wave];
+__device__ __forceinline__ void lk_track_point(const LkArgs& A, LkWaveLds& S, const int slot, const int p, const int lane) {
   const size_t pidx = (size_t)slot * A.maxpts + p;
   const float ptx = A.prev_pts[2 * pidx], pty = A.prev_pts[2 * pidx + 1];
   const float FLT_SCALE = 1.f / (1 << 20);
@@ -497,6 +500,32 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs A) {
   }
 }
 
+__global__ __launch_bounds__(256) void lk_track_kernel(LkArgs A) {
+  __shared__ LkWaveLds lds[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  LkWaveLds& S = lds[wave];
+  if (A.work_slot) {
+    const int total = min(max(A.pt_base[A.nslots], 0), A.nslots * A.maxpts);
+    for (;;) {   // every wavefront leaves once the counter has passed the item count
+      int w0 = 0;
+      if (lane == 0) w0 = atomicAdd(A.work_ctr, LK_CHUNK);
+      w0 = __builtin_amdgcn_readfirstlane(w0);
+      if (w0 >= total) break;
+      const int w1 = min(w0 + LK_CHUNK, total);
+      for (int w = w0; w < w1; w++) {
+        const int slot = min(max(A.work_slot[w], 0), A.nslots - 1);
+        const int p = w - A.pt_base[slot];
+        if (p >= 0 && p < A.maxpts) lk_track_point(A, S, slot, p, lane);   // always true for a consistent list
+      }
+    }
+    return;
+  }
+  const int slot = blockIdx.y;
+  const int p = blockIdx.x * 4 + wave;
+  if (p >= min(A.npts[slot], A.maxpts)) return;  // wave-uniform
+  lk_track_point(A, S, slot, p, lane);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
@@ -516,10 +545,12 @@ int lk_build_pyramid(mvo_ctx* ctx, int set, const LkLevels& L, int nslots, hipSt
 }
 
 // Track d_prev_pts -> d_next_pts for `nslots` slots between pyramid sets prev_set and cur_set.
-int lk_track_device(mvo_ctx* ctx, int prev_set, int cur_set, const LkLevels& L, int nslots, int max_n, hipStream_t st) {
+int lk_track_device(mvo_ctx* ctx, int prev_set, int cur_set, const LkLevels& L, int nslots, int max_n, hipStream_t st,
+                    const int* d_work_slot, const int* d_pt_base, int* d_work_ctr) {
   if (!st) st = ctx->stream;
   LkArgs A;
   memset(&A, 0, sizeof(A));
+  A.work_slot = d_work_slot; A.pt_base = d_pt_base; A.work_ctr = d_work_ctr; A.nslots = nslots;
   for (int l = 0; l < L.n; l++) {
     ImgSet p = lk_imgset(ctx, prev_set, L, l), c = lk_imgset(ctx, cur_set, L, l);
     A.lv[l].I = p.base; A.lv[l].J = c.base;
@@ -536,6 +567,12 @@ int lk_track_device(mvo_ctx* ctx, int prev_set, int cur_set, const LkLevels& L, 
   A.max_count = mc;
   A.eps2 = eps * eps;
   A.min_eig = ctx->cfg.lk_min_eig;
+  if (d_work_slot) {
+    // persistent wavefronts: 5 workgroups of 4 per CU is what the kernel's registers allow (256 CUs)
+    const unsigned want = ((unsigned)nslots * (unsigned)ctx->maxpts + 4 * LK_CHUNK - 1) / (4 * LK_CHUNK);
+    hipLaunchKernelGGL(lk_track_kernel, dim3(want < 1280u ? want : 1280u), dim3(256), 0, st, A);
+    return MVO_OK;
+  }
   if (max_n <= 0) return MVO_OK;
   dim3 grid((max_n + 3) / 4, nslots);
   hipLaunchKernelGGL(lk_track_kernel, grid, dim3(256), 0, st, A);

@@ -14,9 +14,12 @@
 
 __global__ __launch_bounds__(256) void hamming_knn2_kernel(const u8* __restrict__ q, const u8* __restrict__ t,
                                                            const int* __restrict__ nq_, const int* __restrict__ nt_,
-                                                           unsigned* __restrict__ best, int cap) {
+                                                           unsigned* __restrict__ best, int cap,
+                                                           const int* __restrict__ list, const int* __restrict__ nlist) {
   __shared__ uint4 s_t[MT_TILE * 2];
-  const int slot = blockIdx.y;
+  // `list` (optional): blockIdx.y indexes a device-resident list of *nlist slots (the key-frame slots of this step)
+  if (list && (int)blockIdx.y >= *nlist) return;   // block-uniform
+  const int slot = list ? list[blockIdx.y] : blockIdx.y;
   const int nq = min(nq_[slot], cap), nt = min(nt_[slot], cap);
   const int qi = blockIdx.x * 256 + threadIdx.x;
   if (blockIdx.x * 256 >= nq) return;  // block-uniform
@@ -48,10 +51,11 @@ __global__ __launch_bounds__(256) void hamming_knn2_kernel(const u8* __restrict_
 __global__ __launch_bounds__(1024) void ratio_compact_kernel(const unsigned* __restrict__ best,
                                                              const int* __restrict__ nq_, double ratio,
                                                              mvo_match* __restrict__ out, int* __restrict__ nout,
-                                                             int cap) {
+                                                             int cap, const int* __restrict__ list, const int* __restrict__ nlist) {
   __shared__ int s_wave[16];
   __shared__ int s_base;
-  const int slot = blockIdx.x;
+  if (list && (int)blockIdx.x >= *nlist) return;   // block-uniform
+  const int slot = list ? list[blockIdx.x] : blockIdx.x;
   const int nq = min(nq_[slot], cap);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) s_base = 0;
@@ -115,15 +119,15 @@ void match_state_destroy(mvo_ctx* ctx) {
 }
 
 // Device-side matcher over `nslots` slots: d_q/d_t/d_nq/d_nt already resident.
-int match_device(mvo_ctx* ctx, int nslots, int max_nq, double ratio) {
+int match_device(mvo_ctx* ctx, int nslots, int max_nq, double ratio, const int* d_list, const int* d_nlist) {
   MatchState* m = ctx->match;
   if (max_nq > 0) {
     dim3 grid((max_nq + 255) / 256, nslots);
     hipLaunchKernelGGL(hamming_knn2_kernel, grid, dim3(256), 0, ctx->stream, m->d_q, m->d_t, m->d_nq, m->d_nt,
-                       m->d_best, m->cap);
+                       m->d_best, m->cap, d_list, d_nlist);
   }
   hipLaunchKernelGGL(ratio_compact_kernel, dim3(nslots), dim3(1024), 0, ctx->stream, m->d_best, m->d_nq, ratio,
-                     m->d_out, m->d_nout, m->cap);
+                     m->d_out, m->d_nout, m->cap, d_list, d_nlist);
   return MVO_OK;
 }
 

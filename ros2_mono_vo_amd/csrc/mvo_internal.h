@@ -174,6 +174,48 @@ struct GeomState {
 };
 
 
+// ---- frame-batch pipeline state (pipeline.hip, track.hip) --------------------------------------------
+struct PipeState {
+  int ring = 0;
+  int w = 0, h = 0, pitch = 0;  // geometry of the frames in the ring (fixed by the first preload)
+  size_t frame_bytes = 0;       // one slot's frame
+  u8* d_ring = nullptr;         // [ring][B][h][pitch]
+  float* d_lm = nullptr;        // [B][maxpts][3] landmark of each tracked point
+  float* d_kf_pts = nullptr;    // [B][maxpts][2] last key-frame position of each tracked point
+  float* d_cur_pts = nullptr;   // compacted survivors of LK
+  float* d_cur_lm = nullptr;
+  float* d_cur_kf = nullptr;
+  int* d_ncur = nullptr;        // [B]
+  float* d_kp_xy = nullptr;     // [B][maxpts][2] key-point positions of the current frame (match train side)
+  float* d_kfkp_xy = nullptr;   // [B][maxpts][2] key-point positions of the last key-frame (match query side)
+  int* h_ints = nullptr;        // pinned scratch
+  double K[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  double dist[5] = {0, 0, 0, 0, 0};
+  bool seeded = false;
+  // landmark hand-over (device-resident Frame/KeyFrame bookkeeping, src/tracker.cpp:193-234)
+  u8* d_kf_has = nullptr;     // [B][maxpts] key-frame observation has a landmark
+  float* d_kf_lm = nullptr;   // [B][maxpts][3]
+  u8* d_cur_has = nullptr;
+  float* d_cur_lmk = nullptr; // [B][maxpts][3]
+  int* d_winner = nullptr;    // [B][maxpts] last valid match per current key-point
+  float* d_tri = nullptr;     // [B][maxpts][3] triangulated matches
+  u8* d_tri_ok = nullptr;     // [B][maxpts]
+  double* d_kf_pose = nullptr;  // [B][8] T_cw of the last key-frame (rvec, tvec)
+  int* d_ntri = nullptr;      // [B]
+  // side streams: the latency-bound RANSAC chains run beside ORB (they only depend on the LK survivors)
+  // s_lk carries pyramid + LK + filter (high priority: the RANSAC chains hang off it), main stream carries ORB.
+  hipStream_t s_lk = nullptr, s_pnp = nullptr, s_hf = nullptr;
+  hipEvent_t ev_frame = nullptr, ev_lktrack = nullptr, ev_lk = nullptr, ev_pnp = nullptr, ev_hf = nullptr;
+  int trk_max_n = 0;  // host-side bound on the per-slot track count (grid sizing)
+  int kf_max_n = 0;   // host-side bound on the key-frame descriptor count
+  struct TrackState* trk = nullptr;  // device-driven per-stream tracker (track.hip)
+  // asynchronous ingest (track.hip): uploads run on their own stream; ev_up[f] = frame f of the ring has landed,
+  // ev_rd[f] = the step that consumed frame f has read it (a later upload into that ring entry waits for it)
+  hipStream_t s_up = nullptr;
+  std::vector<hipEvent_t> ev_up, ev_rd;
+  std::vector<char> up_pending, rd_pending;
+};
+
 // Level geometry helpers (host).
 struct LkLevels {
   int n;  // number of levels actually used (maxLevel+1 after the <= winSize early stop)
@@ -190,10 +232,14 @@ int geom_state_create(mvo_ctx* ctx);
 void geom_state_destroy(mvo_ctx* ctx);
 int pipe_state_create(mvo_ctx* ctx);
 void pipe_state_destroy(mvo_ctx* ctx);
+void trk_destroy(mvo_ctx* ctx);   // track.hip
+int trk_reset(mvo_ctx* ctx);
+void lk_filter_compact_launch(mvo_ctx* ctx, hipStream_t st);   // pipeline.hip: status/err filter of all slots
 
 // device-level stage drivers (all slots per launch)
 int lk_build_pyramid(mvo_ctx* ctx, int set, const LkLevels& L, int nslots, hipStream_t st = nullptr);
-int lk_track_device(mvo_ctx* ctx, int prev_set, int cur_set, const LkLevels& L, int nslots, int max_n, hipStream_t st = nullptr);
+int lk_track_device(mvo_ctx* ctx, int prev_set, int cur_set, const LkLevels& L, int nslots, int max_n, hipStream_t st = nullptr,
+                    const int* d_work_slot = nullptr, const int* d_pt_base = nullptr, int* d_work_ctr = nullptr);
 // ORB in three phases on ctx->stream so that a caller can put other GPU work beside the host-side selection:
 //   orb_detect_enqueue  pyramid, FAST+NMS, ordered compaction, async copy of the counts           (no host wait)
 //   orb_select          waits for the counts (capacity check, grid size), Harris, OpenCV's two retainBest passes per
@@ -205,8 +251,10 @@ int orb_detect_enqueue(mvo_ctx* ctx, int w, int h, int nslots, hipEvent_t before
 int orb_select(mvo_ctx* ctx, int w, int h, int nslots, bool describe, std::vector<int>& kp_base);
 int orb_describe_enqueue(mvo_ctx* ctx, int w, int h, int nslots, bool describe, bool to_host, const std::vector<int>& kp_base);
 int orb_run(mvo_ctx* ctx, int w, int h, int nslots, bool describe, std::vector<int>& kp_base);
-int orb_select_device(mvo_ctx* ctx, const OrbGeom& G, int nslots);  // orb_select.hip: both retainBest passes + dense gather
-int match_device(mvo_ctx* ctx, int nslots, int max_nq, double ratio);
+int orb_select_device(mvo_ctx* ctx, const OrbGeom& G, int nslots, const int* d_nact = nullptr);  // orb_select.hip: both retainBest passes + dense gather
+int orb_run_device(mvo_ctx* ctx, int w, int h, int max_slots, const int* d_nact);  // device-driven detect + describe (no host wait)
+// d_list / d_nlist (optional): run only the *d_nlist slots named by the device-resident list (grid sized for nslots)
+int match_device(mvo_ctx* ctx, int nslots, int max_nq, double ratio, const int* d_list = nullptr, const int* d_nlist = nullptr);
 int geom_ransac_h(mvo_ctx* ctx, int nslots, const float* p1, const float* p2, const int* d_n, double thr, int max_iters, double conf,
                   u8* mask, double* model, int* result, hipStream_t st);
 int geom_ransac_f(mvo_ctx* ctx, int nslots, const float* p1, const float* p2, const int* d_n, double thr, int max_iters, double conf,
@@ -215,7 +263,8 @@ int geom_pnp(mvo_ctx* ctx, int nslots, const float* obj, const float* img, const
              float reproj, double conf, u8* mask, double* model, int* result, int* inl, double* pose, hipStream_t st);
 int geom_triangulate_matches(mvo_ctx* ctx, int nslots, int max_matches, const mvo_match* matches, const int* n_matches,
                              const float* kf_xy, const float* cur_xy, const double* kf_pose, const double* cur_pose,
-                             const int* pnp_result, const double K[9], float* X3, u8* valid);
+                             const int* pnp_result, const double K[9], float* X3, u8* valid, const int* d_list = nullptr,
+                             const int* d_nlist = nullptr);
 
 // Upload a host image (mono8 or BGR8, arbitrary stride) into a device mono8 ImgSet slot (async on ctx->stream).
 int upload_gray(mvo_ctx* ctx, const uint8_t* img, int w, int h, int stride, int channels, u8* d_dst,
@@ -241,9 +290,14 @@ static inline unsigned xcd_grid_blocks(const TileGrid& g) {
   unsigned n = (unsigned)g.gx * g.gy * g.gz;
   return ((n + 7) / 8) * 8;
 }
-__device__ __forceinline__ bool xcd_tile(const TileGrid& g, int& tx, int& ty, int& tz) {
+// Launch width of the device-driven (count read on the device) image kernels: workgroups loop over the tile list with a
+// stride of the grid, so a launch never needs the host to know how many slots are active.  8 workgroups per CU and a
+// multiple of 8 (b % 8 = XCD stays fixed over a workgroup's iterations).
+#define MVO_PERSIST_BLOCKS 2048u
+static inline unsigned persist_grid(unsigned want) { return want < MVO_PERSIST_BLOCKS ? want : MVO_PERSIST_BLOCKS; }
+// tile of linear workgroup index b (b = blockIdx.x in a one-tile-per-workgroup launch, the loop variable in a strided one)
+__device__ __forceinline__ bool xcd_tile_b(const TileGrid& g, unsigned b, int& tx, int& ty, int& tz) {
   const unsigned n = (unsigned)g.gx * g.gy * g.gz, per = (n + 7) / 8;
-  const unsigned b = blockIdx.x;
   const unsigned t = (b & 7u) * per + (b >> 3);
   if (t >= n) return false;
   const unsigned row = t / g.gx;
@@ -251,6 +305,11 @@ __device__ __forceinline__ bool xcd_tile(const TileGrid& g, int& tx, int& ty, in
   tz = (int)(row / g.gy);
   ty = (int)(row - (unsigned)tz * g.gy);
   return true;
+}
+__device__ __forceinline__ bool xcd_tile(const TileGrid& g, int& tx, int& ty, int& tz) { return xcd_tile_b(g, blockIdx.x, tx, ty, tz); }
+__device__ __forceinline__ unsigned xcd_grid_blocks_dev(const TileGrid& g) {
+  const unsigned n = (unsigned)g.gx * g.gy * g.gz;
+  return ((n + 7) / 8) * 8;
 }
 __device__ __forceinline__ int d_cv_round(float v) { return __float2int_rn(v); }
 __device__ __forceinline__ int d_cv_round(double v) { return __double2int_rn(v); }

@@ -105,13 +105,21 @@ __device__ __forceinline__ int lin_ofs(double scale, int src, int v) {
   return 0;
 }
 
-__global__ __launch_bounds__(256) void resize_exact_kernel(const u8* __restrict__ pyr, size_t slot_stride, size_t soff, int spitch,
-                                                           int sw, int sh, size_t doff, int dpitch, int dw, int dh, double scale_x,
-                                                           double scale_y, const unsigned* __restrict__ xtab,
-                                                           const unsigned* __restrict__ ytab, TileGrid tg) {
-  __shared__ unsigned s_src[RZ_SH * RZ_SP / 4];
+struct ResizeArgs {
+  const u8* pyr; size_t slot_stride, soff; int spitch, sw, sh; size_t doff; int dpitch, dw, dh; double scale_x, scale_y;
+  const unsigned* xtab; const unsigned* ytab; TileGrid tg;
+  const int* nact;   // optional device count of active slots (<= tg.gz); the launch is then a strided loop over the tiles
+};
+
+__device__ __forceinline__ void resize_exact_tile(const ResizeArgs& A, const TileGrid& tg, unsigned b, unsigned* s_src) {
+  const u8* __restrict__ pyr = A.pyr;
+  const size_t slot_stride = A.slot_stride, soff = A.soff, doff = A.doff;
+  const int spitch = A.spitch, sw = A.sw, sh = A.sh, dpitch = A.dpitch, dw = A.dw, dh = A.dh;
+  const double scale_x = A.scale_x, scale_y = A.scale_y;
+  const unsigned* __restrict__ xtab = A.xtab;
+  const unsigned* __restrict__ ytab = A.ytab;
   int bx, by, bz;
-  if (!xcd_tile(tg, bx, by, bz)) return;
+  if (!xcd_tile_b(tg, b, bx, by, bz)) return;
   const u8* sp = pyr + (size_t)bz * slot_stride + soff;
   u8* dp = const_cast<u8*>(pyr) + (size_t)bz * slot_stride + doff;
   const int x0 = bx * RZ_W, y0 = by * RZ_H, tid = threadIdx.x;
@@ -168,6 +176,17 @@ __global__ __launch_bounds__(256) void resize_exact_kernel(const u8* __restrict_
       }
     }
     *(unsigned*)(dp + (size_t)__umul24(y, dpitch) + x) = out;  // x % 4 == 0 and pitch % 64 == 0: the padding columns take zeros
+  }
+}
+
+__global__ __launch_bounds__(256) void resize_exact_kernel(ResizeArgs A) {
+  __shared__ unsigned s_src[RZ_SH * RZ_SP / 4];
+  TileGrid tg = A.tg;
+  if (A.nact) tg.gz = min(tg.gz, max(*A.nact, 0));
+  const unsigned nb = xcd_grid_blocks_dev(tg);
+  for (unsigned b = blockIdx.x; b < nb; b += gridDim.x) {
+    resize_exact_tile(A, tg, b, s_src);
+    __syncthreads();   // the next tile reuses the LDS tile
   }
 }
 
@@ -276,6 +295,16 @@ struct FastArgs {
   u8* seg_cnt;   // [slots][max_rows][seg_per_row], zeroed before the launch: survivors per 64-pixel row segment
   int seg_per_row;
   TileGrid tg;
+  const int* nact;   // optional device count of active slots (see ResizeArgs)
+};
+
+struct FastLds {
+  unsigned px[FT_PR * FT_PD];
+  unsigned sc[FT_SR * FT_PD];
+  unsigned short list[FT_SR * (FT_W + 2) + 64];
+  unsigned short list2[FT_SR * (FT_W + 2) + 64];
+  unsigned rowmask[FT_H][2];
+  int n, n2;
 };
 
 // FAST-9/16 + cornerScore + strict 3x3 NMS for one 64x32 tile, plus the per-row survivor counts of the ordered
@@ -283,15 +312,16 @@ struct FastArgs {
 // phase 2a runs the 16-pixel arc test on the compacted candidates and compacts the corners (about 2 % of the pixels),
 // phase 2b scores those, phase 3 is the NMS of the corners (list driven, not a pass over the tile), phase 4 writes the
 // survivors of each tile row in x order.
-__global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs A) {
-  __shared__ unsigned s_px[FT_PR * FT_PD];
-  __shared__ unsigned s_sc[FT_SR * FT_PD];
-  __shared__ unsigned short s_list[FT_SR * (FT_W + 2) + 64];
-  __shared__ unsigned short s_list2[FT_SR * (FT_W + 2) + 64];
-  __shared__ unsigned s_rowmask[FT_H][2];
-  __shared__ int s_n, s_n2;
+__device__ __forceinline__ void fast_nms_tile(const FastArgs& A, const TileGrid& tg, unsigned b, FastLds& L) {
+  unsigned* s_px = L.px;
+  unsigned* s_sc = L.sc;
+  unsigned short* s_list = L.list;
+  unsigned short* s_list2 = L.list2;
+  unsigned (*s_rowmask)[2] = L.rowmask;
+  int& s_n = L.n;
+  int& s_n2 = L.n2;
   int bx, by, bz;
-  if (!xcd_tile(A.tg, bx, by, bz)) return;
+  if (!xcd_tile_b(tg, b, bx, by, bz)) return;
   const u8* sp = A.pyr + (size_t)bz * A.slot_stride + A.off;
   u8* dp = A.score + (size_t)bz * A.slot_stride + A.off;
   const int w = A.w, h = A.h, pitch = A.pitch, lo = A.lo;
@@ -465,6 +495,17 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs A) {
   }
 }
 
+__global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs A) {
+  __shared__ FastLds L;
+  TileGrid tg = A.tg;
+  if (A.nact) tg.gz = min(tg.gz, max(*A.nact, 0));
+  const unsigned nb = xcd_grid_blocks_dev(tg);
+  for (unsigned b = blockIdx.x; b < nb; b += gridDim.x) {
+    fast_nms_tile(A, tg, b, L);
+    __syncthreads();   // the next tile reuses the LDS tile, lists and counters
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // ordered emit of the NMS survivors (row-major per level): one wavefront per image row, one lane per 64-pixel
 // segment; counts from seg_cnt, offsets from scan_rows / scan_slots, records from the head of each segment
@@ -474,11 +515,17 @@ template <int RPW>
 __global__ __launch_bounds__(256) void nms_rows_kernel(const u8* __restrict__ score, const u8* __restrict__ seg_cnt, int seg_per_row,
                                                        OrbGeom G, const int* __restrict__ row_off, const int* __restrict__ slot_base,
                                                        int max_rows, unsigned short* __restrict__ cx, unsigned short* __restrict__ cy,
-                                                       u8* __restrict__ cs, u8* __restrict__ cl, int* __restrict__ cslot, int cand_cap) {
+                                                       u8* __restrict__ cs, u8* __restrict__ cl, int* __restrict__ cslot, int cand_cap,
+                                                       int row_blocks, int nslots, const int* __restrict__ nact) {
   constexpr int LPR = 64 / RPW;  // lanes per row
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane & (LPR - 1);
-  const int slot = blockIdx.y;
-  const int row = (blockIdx.x * 4 + wave) * RPW + lane / LPR;
+  // work item = (row block, slot); a strided loop when the slot count lives on the device
+  const int nslots_act = nact ? min(max(*nact, 0), nslots) : nslots;
+  const unsigned total = (unsigned)row_blocks * (unsigned)nslots_act;
+  for (unsigned wi = blockIdx.x; wi < total; wi += gridDim.x) {
+  const int slot = (int)(wi / (unsigned)row_blocks);
+  const int rb = (int)(wi - (unsigned)slot * (unsigned)row_blocks);
+  const int row = (rb * 4 + wave) * RPW + lane / LPR;
   const bool live = row < G.row0[G.nlevels];
   int l = 0;
 #pragma unroll
@@ -495,7 +542,7 @@ __global__ __launch_bounds__(256) void nms_rows_kernel(const u8* __restrict__ sc
     int t = __shfl_up(incl, d, LPR);
     if (sub >= d) incl += t;
   }
-  if (cnt == 0) return;
+  if (cnt == 0) continue;
   int o = slot_base[slot] + row_off[rowi] + incl - cnt;
   const unsigned short* rec = (const unsigned short*)(score + (size_t)slot * G.slot_stride + G.off[l] + (size_t)y * pitch + sub * 64);
   for (int k = 0; k < cnt; k++, o++) {
@@ -503,29 +550,46 @@ __global__ __launch_bounds__(256) void nms_rows_kernel(const u8* __restrict__ sc
     const unsigned r = rec[k];
     cx[o] = (unsigned short)(sub * 64 + (r >> 8)); cy[o] = (unsigned short)y; cs[o] = (u8)(r & 0xFFu); cl[o] = (u8)l; cslot[o] = slot;
   }
+  }
 }
 
-static void nms_rows_launch(mvo_ctx* ctx, const OrbGeom& G, int nrows, int nslots) {
+static void nms_rows_launch(mvo_ctx* ctx, const OrbGeom& G, int nrows, int nslots, const int* d_nact = nullptr) {
   OrbState* o = ctx->orb;
   if (nrows <= 0) return;
   if (o->seg_per_row <= 32) {
-    dim3 grid((nrows + 7) / 8, nslots);
-    hipLaunchKernelGGL(nms_rows_kernel<2>, grid, dim3(256), 0, ctx->stream, o->d_score, o->d_seg_cnt, o->seg_per_row, G, o->d_row_off,
-                       o->d_slot_base, o->max_rows, o->d_cx, o->d_cy, o->d_cs, o->d_cl, o->d_cslot, o->cand_cap);
+    const int rb = (nrows + 7) / 8;
+    const unsigned total = (unsigned)rb * nslots;
+    hipLaunchKernelGGL(nms_rows_kernel<2>, dim3(d_nact ? persist_grid(total) : total), dim3(256), 0, ctx->stream, o->d_score, o->d_seg_cnt,
+                       o->seg_per_row, G, o->d_row_off, o->d_slot_base, o->max_rows, o->d_cx, o->d_cy, o->d_cs, o->d_cl, o->d_cslot,
+                       o->cand_cap, rb, nslots, d_nact);
   } else {
-    dim3 grid((nrows + 3) / 4, nslots);
-    hipLaunchKernelGGL(nms_rows_kernel<1>, grid, dim3(256), 0, ctx->stream, o->d_score, o->d_seg_cnt, o->seg_per_row, G, o->d_row_off,
-                       o->d_slot_base, o->max_rows, o->d_cx, o->d_cy, o->d_cs, o->d_cl, o->d_cslot, o->cand_cap);
+    const int rb = (nrows + 3) / 4;
+    const unsigned total = (unsigned)rb * nslots;
+    hipLaunchKernelGGL(nms_rows_kernel<1>, dim3(d_nact ? persist_grid(total) : total), dim3(256), 0, ctx->stream, o->d_score, o->d_seg_cnt,
+                       o->seg_per_row, G, o->d_row_off, o->d_slot_base, o->max_rows, o->d_cx, o->d_cy, o->d_cs, o->d_cl, o->d_cslot,
+                       o->cand_cap, rb, nslots, d_nact);
   }
+}
+
+// zero the per-row / per-segment survivor counts of the first *nact slots (16-byte stores; the ranges are rounded up, which
+// only touches counts of inactive slots - or the 16 bytes of slack behind the last slot)
+__global__ __launch_bounds__(256) void orb_zero_counts_kernel(uint4* __restrict__ a, size_t a_bytes_per_slot, uint4* __restrict__ b,
+                                                              size_t b_bytes_per_slot, const int* __restrict__ nact, int nslots) {
+  const int n = min(max(*nact, 0), nslots);
+  const size_t na = ((size_t)n * a_bytes_per_slot + 15) / 16, nb = ((size_t)n * b_bytes_per_slot + 15) / 16;
+  const uint4 z = make_uint4(0, 0, 0, 0);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < na; i += (size_t)gridDim.x * 256) a[i] = z;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += (size_t)gridDim.x * 256) b[i] = z;
 }
 
 // one block per slot: exclusive scan of the row counts (rows of all levels in order), per-level totals.
 __global__ __launch_bounds__(1024) void scan_rows_kernel(const int* __restrict__ row_cnt, int* __restrict__ row_off,
                                                          OrbGeom G, int max_rows, int* __restrict__ lvl_cnt,
-                                                         int* __restrict__ slot_tot) {
+                                                         int* __restrict__ slot_tot, const int* __restrict__ nact) {
   __shared__ int s_w[16];
   __shared__ int s_run;
   const int slot = blockIdx.x;
+  if (nact && slot >= *nact) return;   // block-uniform
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nrows = G.row0[G.nlevels];
   if (threadIdx.x == 0) s_run = 0;
@@ -564,8 +628,9 @@ __global__ __launch_bounds__(1024) void scan_rows_kernel(const int* __restrict__
   }
 }
 
-__global__ void scan_slots_kernel(const int* __restrict__ slot_tot, int* __restrict__ slot_base, int nslots) {
+__global__ void scan_slots_kernel(const int* __restrict__ slot_tot, int* __restrict__ slot_base, int nslots, const int* __restrict__ nact) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
+    if (nact) nslots = min(max(*nact, 0), nslots);
     int run = 0;
     for (int s = 0; s < nslots; s++) { slot_base[s] = run; run += slot_tot[s]; }
     slot_base[nslots] = run;
@@ -616,13 +681,22 @@ struct __attribute__((aligned(16))) BriefRec {
   int pad[3];
 };
 
+// `nsel_dev` (optional): the key-point count lives on the device (kp_base[*nact], clamped to nsel = capacity) and the
+// launch is a strided loop over groups of 8 key-points.
+__device__ __forceinline__ int orb_nsel(int nsel, const int* __restrict__ kp_base, const int* __restrict__ nact) {
+  return kp_base ? min(max(kp_base[max(*nact, 0)], 0), nsel) : nsel;
+}
+
 __global__ __launch_bounds__(256) void ic_angle_kernel(const u8* __restrict__ pyr, OrbGeom G, const int* __restrict__ sel,
                                                        int nsel, const unsigned short* __restrict__ cx,
                                                        const unsigned short* __restrict__ cy, const u8* __restrict__ cl,
                                                        const int* __restrict__ cslot, const float* __restrict__ ch,
-                                                       const unsigned* __restrict__ icmask /* [16][9] */, mvo_keypoint* __restrict__ kp) {
+                                                       const unsigned* __restrict__ icmask /* [16][9] */, mvo_keypoint* __restrict__ kp,
+                                                       const int* __restrict__ kp_base, const int* __restrict__ nact) {
+  nsel = orb_nsel(nsel, kp_base, nact);
   const int lane = threadIdx.x & 63, sub = lane & 31;
-  const int k = blockIdx.x * 8 + (threadIdx.x >> 5);
+  for (int g0 = blockIdx.x * 8; g0 < nsel; g0 += gridDim.x * 8) {
+  const int k = g0 + (threadIdx.x >> 5);
   const bool live = k < nsel;
   int m10 = 0, m01 = 0, ci = 0, l = 0, x0 = 0, y0 = 0;
   if (live) {
@@ -665,6 +739,7 @@ __global__ __launch_bounds__(256) void ic_angle_kernel(const u8* __restrict__ py
     o.class_id = -1;
     kp[k] = o;
   }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -679,12 +754,19 @@ typedef unsigned short bl_ushort2 __attribute__((ext_vector_type(2)));
 
 // Separable 7-tap blur, all-integer: horizontal taps by v_alignbyte + 2 x v_dot4_u32_u8 per pixel (4 pixels per lane),
 // row sums (<= 257*255, fit u16) stored transposed in LDS, vertical taps by 4 x v_dot2_u32_u16, (s + 2^15) >> 16.
-__global__ __launch_bounds__(256) void blur7_kernel(const u8* __restrict__ pyr, u8* __restrict__ out, size_t slot_stride,
-                                                    size_t off, int w, int h, int pitch, BlurTaps T, TileGrid tg) {
-  __shared__ unsigned s_src[(BL_H + 6) * BL_SP / 4];
-  __shared__ unsigned short s_h[BL_W * BL_HP];
+struct BlurArgs {
+  const u8* pyr; u8* out; size_t slot_stride, off; int w, h, pitch; BlurTaps T; TileGrid tg;
+  const int* nact;   // optional device count of active slots (see ResizeArgs)
+};
+
+__device__ __forceinline__ void blur7_tile(const BlurArgs& A, const TileGrid& tg, unsigned b, unsigned* s_src, unsigned short* s_h) {
+  const u8* __restrict__ pyr = A.pyr;
+  u8* __restrict__ out = A.out;
+  const size_t slot_stride = A.slot_stride, off = A.off;
+  const int w = A.w, h = A.h, pitch = A.pitch;
+  const BlurTaps& T = A.T;
   int bx, by, bz;
-  if (!xcd_tile(tg, bx, by, bz)) return;
+  if (!xcd_tile_b(tg, b, bx, by, bz)) return;
   const u8* sp = pyr + (size_t)bz * slot_stride + off;
   u8* dp = out + (size_t)bz * slot_stride + off;
   const int x0 = bx * BL_W, y0 = by * BL_H;
@@ -776,15 +858,28 @@ __global__ __launch_bounds__(256) void blur7_kernel(const u8* __restrict__ pyr, 
   }
 }
 
+__global__ __launch_bounds__(256) void blur7_kernel(BlurArgs A) {
+  __shared__ unsigned s_src[(BL_H + 6) * BL_SP / 4];
+  __shared__ unsigned short s_h[BL_W * BL_HP];
+  TileGrid tg = A.tg;
+  if (A.nact) tg.gz = min(tg.gz, max(*A.nact, 0));
+  const unsigned nb = xcd_grid_blocks_dev(tg);
+  for (unsigned b = blockIdx.x; b < nb; b += gridDim.x) {
+    blur7_tile(A, tg, b, s_src, s_h);
+    __syncthreads();   // the next tile reuses both LDS tiles
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // rotated BRIEF: 2 key-points per wavefront, one descriptor byte per lane
 // ---------------------------------------------------------------------------------------------------
 // One lane per key-point: the records rBRIEF works from (64 sin / cos pairs per wavefront instead of one per half-wave).
 __global__ __launch_bounds__(256) void brief_rec_kernel(OrbGeom G, const int* __restrict__ sel, int nsel, const u8* __restrict__ cl,
                                                         const int* __restrict__ cslot, const mvo_keypoint* __restrict__ kp,
-                                                        BriefRec* __restrict__ rec) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= nsel) return;
+                                                        BriefRec* __restrict__ rec, const int* __restrict__ kp_base,
+                                                        const int* __restrict__ nact) {
+  nsel = orb_nsel(nsel, kp_base, nact);
+  for (int k = blockIdx.x * 256 + threadIdx.x; k < nsel; k += gridDim.x * 256) {
   const int ci = sel[k], l = cl[ci];
   const mvo_keypoint kpt = kp[k];
   // computeOrbDescriptors: centre = cvRound(kpt.pt * (1 / scale)) in the level image, angle in radians as float
@@ -799,6 +894,7 @@ __global__ __launch_bounds__(256) void brief_rec_kernel(OrbGeom G, const int* __
   r.b = (float)sin((double)angle);
   r.pad[0] = r.pad[1] = r.pad[2] = 0;
   rec[k] = r;
+  }
 }
 
 // 32 lanes per key-point, one descriptor byte per lane.  The rotated pattern stays within +-19 pixels of the centre
@@ -809,12 +905,15 @@ __global__ __launch_bounds__(256) void brief_rec_kernel(OrbGeom G, const int* __
 #define BR_ROWS (2 * BR_R + 1)
 #define BR_LP 64   // LDS row pitch in bytes: 48 staged + pad, keeps the 16-byte stores aligned
 __global__ __launch_bounds__(256) void brief_kernel(const u8* __restrict__ blur, const BriefRec* __restrict__ rec, int nsel,
-                                                    const char4* __restrict__ pattern, u8* __restrict__ desc) {
+                                                    const char4* __restrict__ pattern, u8* __restrict__ desc,
+                                                    const int* __restrict__ kp_base, const int* __restrict__ nact) {
   __shared__ char4 s_pat[256];
   __shared__ uint4 s_patch[8][BR_ROWS * BR_LP / 16];
+  nsel = orb_nsel(nsel, kp_base, nact);
   s_pat[threadIdx.x] = pattern[threadIdx.x];
   const int h = threadIdx.x >> 5, byte = threadIdx.x & 31;
-  const int k = blockIdx.x * 8 + h;
+  for (int g0 = blockIdx.x * 8; g0 < nsel; g0 += gridDim.x * 8) {   // block-uniform trip count
+  const int k = g0 + h;
   const bool live = k < nsel;
   BriefRec r;
   r.off = 0; r.pitch = 0; r.a = 0.f; r.b = 0.f;
@@ -830,7 +929,7 @@ __global__ __launch_bounds__(256) void brief_kernel(const u8* __restrict__ blur,
     }
   }
   __syncthreads();
-  if (!live) return;
+  if (live) {
   const float a = r.a, b = r.b;
   const u8* c = (const u8*)s_patch[h] + BR_R * BR_LP + BR_R + shift;
   int val = 0;
@@ -844,6 +943,9 @@ __global__ __launch_bounds__(256) void brief_kernel(const u8* __restrict__ blur,
     val |= (t0 < t1) << t;
   }
   desc[(size_t)k * 32 + byte] = (u8)val;
+  }
+  __syncthreads();   // the next group of key-points reuses the patches
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -860,10 +962,10 @@ int orb_state_create(mvo_ctx* ctx) {
   MVO_HIP(hipMalloc(&o->d_pyr, tot));
   MVO_HIP(hipMalloc(&o->d_score, tot));
   MVO_HIP(hipMalloc(&o->d_blur, tot));
-  MVO_HIP(hipMalloc(&o->d_row_cnt, (size_t)ctx->B * o->max_rows * sizeof(int)));
+  MVO_HIP(hipMalloc(&o->d_row_cnt, (size_t)ctx->B * o->max_rows * sizeof(int) + 16));
   o->seg_per_row = (ctx->maxw + 63) / 64;
   if (o->seg_per_row > 64) { ctx->set_error("max_width above 4096 is not supported by the ORB emit pass"); return MVO_E_ARG; }
-  MVO_HIP(hipMalloc(&o->d_seg_cnt, (size_t)ctx->B * o->max_rows * o->seg_per_row));
+  MVO_HIP(hipMalloc(&o->d_seg_cnt, (size_t)ctx->B * o->max_rows * o->seg_per_row + 16));
   MVO_HIP(hipMalloc(&o->d_row_off, (size_t)ctx->B * o->max_rows * sizeof(int)));
   MVO_HIP(hipMalloc(&o->d_lvl_cnt, (size_t)ctx->B * MVO_ORB_LEVELS * sizeof(int)));
   MVO_HIP(hipMalloc(&o->d_slot_tot, (size_t)ctx->B * sizeof(int)));
@@ -947,9 +1049,10 @@ void orb_state_destroy(mvo_ctx* ctx) {
   ctx->orb = nullptr;
 }
 
-static void fast_nms_launch(mvo_ctx* ctx, const OrbGeom& G, int l, int nslots, int threshold, int lo) {
+static void fast_nms_launch(mvo_ctx* ctx, const OrbGeom& G, int l, int nslots, int threshold, int lo, const int* d_nact = nullptr) {
   OrbState* o = ctx->orb;
   FastArgs A;
+  A.nact = d_nact;
   A.pyr = o->d_pyr; A.score = o->d_score; A.slot_stride = G.slot_stride; A.off = G.off[l];
   A.w = G.w[l]; A.h = G.h[l]; A.pitch = G.pitch[l]; A.threshold = threshold; A.lo = lo;
   // a level with no compaction rows (smaller than the edge band) must not count anything
@@ -957,7 +1060,7 @@ static void fast_nms_launch(mvo_ctx* ctx, const OrbGeom& G, int l, int nslots, i
   A.row_cnt = o->d_row_cnt; A.max_rows = o->max_rows; A.row_first = G.row0[l];
   A.seg_cnt = o->d_seg_cnt; A.seg_per_row = o->seg_per_row;
   A.tg = TileGrid{(G.w[l] + FT_W - 1) / FT_W, (G.h[l] + FT_H - 1) / FT_H, nslots};
-  hipLaunchKernelGGL(fast_nms_kernel, dim3(xcd_grid_blocks(A.tg)), dim3(256), 0, ctx->stream, A);
+  hipLaunchKernelGGL(fast_nms_kernel, dim3(d_nact ? persist_grid(xcd_grid_blocks(A.tg)) : xcd_grid_blocks(A.tg)), dim3(256), 0, ctx->stream, A);
 }
 
 // (Re)build the per-level resize tables when the frame geometry changes.
@@ -995,29 +1098,40 @@ static int orb_resize_tables(mvo_ctx* ctx, const OrbGeom& G) {
 }
 
 // Stage 1 (device): pyramid (level 0 must already be resident in d_pyr), FAST, NMS, compaction, Harris.
-static int orb_detect_device(mvo_ctx* ctx, const OrbGeom& G, int nslots, hipEvent_t before_fast) {
+// `d_nact` (optional): device count of active slots, <= nslots; every launch is then sized for nslots on the host and
+// reads the real count on the device (no host wait anywhere).
+static int orb_detect_device(mvo_ctx* ctx, const OrbGeom& G, int nslots, hipEvent_t before_fast, const int* d_nact = nullptr) {
   OrbState* o = ctx->orb;
   hipStream_t st = ctx->stream;
   int rc = orb_resize_tables(ctx, G);
   if (rc) return rc;
   for (int l = 1; l < G.nlevels; l++) {
-    TileGrid tg{(G.w[l] + RZ_W - 1) / RZ_W, (G.h[l] + RZ_H - 1) / RZ_H, nslots};
-    hipLaunchKernelGGL(resize_exact_kernel, dim3(xcd_grid_blocks(tg)), dim3(256), 0, st, o->d_pyr, G.slot_stride, G.off[l - 1],
-                       G.pitch[l - 1], G.w[l - 1], G.h[l - 1], G.off[l], G.pitch[l], G.w[l], G.h[l], 1.0 / ((double)G.w[l] / G.w[l - 1]),
-                       1.0 / ((double)G.h[l] / G.h[l - 1]), o->d_rtab + o->rtab_x[l], o->d_rtab + o->rtab_y[l], tg);
+    ResizeArgs R;
+    R.pyr = o->d_pyr; R.slot_stride = G.slot_stride; R.soff = G.off[l - 1]; R.spitch = G.pitch[l - 1]; R.sw = G.w[l - 1]; R.sh = G.h[l - 1];
+    R.doff = G.off[l]; R.dpitch = G.pitch[l]; R.dw = G.w[l]; R.dh = G.h[l];
+    R.scale_x = 1.0 / ((double)G.w[l] / G.w[l - 1]); R.scale_y = 1.0 / ((double)G.h[l] / G.h[l - 1]);
+    R.xtab = o->d_rtab + o->rtab_x[l]; R.ytab = o->d_rtab + o->rtab_y[l];
+    R.tg = TileGrid{(G.w[l] + RZ_W - 1) / RZ_W, (G.h[l] + RZ_H - 1) / RZ_H, nslots};
+    R.nact = d_nact;
+    hipLaunchKernelGGL(resize_exact_kernel, dim3(d_nact ? persist_grid(xcd_grid_blocks(R.tg)) : xcd_grid_blocks(R.tg)), dim3(256), 0, st, R);
   }
   // The caller may hold the wide FAST kernels back until some other stream's work is through (the pipeline's LK kernel
   // heads its critical chain and would otherwise share the CUs with FAST half and half).
   if (before_fast) MVO_HIP(hipStreamWaitEvent(st, before_fast, 0));
   // per-row survivor counts are accumulated by the FAST/NMS kernel itself (phase 3)
-  MVO_HIP(hipMemsetAsync(o->d_row_cnt, 0, (size_t)nslots * o->max_rows * sizeof(int), st));
-  MVO_HIP(hipMemsetAsync(o->d_seg_cnt, 0, (size_t)nslots * o->max_rows * o->seg_per_row, st));
-  for (int l = 0; l < G.nlevels; l++) fast_nms_launch(ctx, G, l, nslots, ctx->cfg.fast_threshold, std::max(3, G.edge - 1));
+  if (d_nact) {
+    hipLaunchKernelGGL(orb_zero_counts_kernel, dim3(256), dim3(256), 0, st, (uint4*)o->d_row_cnt, (size_t)o->max_rows * sizeof(int),
+                       (uint4*)o->d_seg_cnt, (size_t)o->max_rows * o->seg_per_row, d_nact, nslots);
+  } else {
+    MVO_HIP(hipMemsetAsync(o->d_row_cnt, 0, (size_t)nslots * o->max_rows * sizeof(int), st));
+    MVO_HIP(hipMemsetAsync(o->d_seg_cnt, 0, (size_t)nslots * o->max_rows * o->seg_per_row, st));
+  }
+  for (int l = 0; l < G.nlevels; l++) fast_nms_launch(ctx, G, l, nslots, ctx->cfg.fast_threshold, std::max(3, G.edge - 1), d_nact);
   int nrows = G.row0[G.nlevels];
   hipLaunchKernelGGL(scan_rows_kernel, dim3(nslots), dim3(1024), 0, st, o->d_row_cnt, o->d_row_off, G, o->max_rows,
-                     o->d_lvl_cnt, o->d_slot_tot);
-  hipLaunchKernelGGL(scan_slots_kernel, dim3(1), dim3(64), 0, st, o->d_slot_tot, o->d_slot_base, nslots);
-  nms_rows_launch(ctx, G, nrows, nslots);
+                     o->d_lvl_cnt, o->d_slot_tot, d_nact);
+  hipLaunchKernelGGL(scan_slots_kernel, dim3(1), dim3(64), 0, st, o->d_slot_tot, o->d_slot_base, nslots, d_nact);
+  nms_rows_launch(ctx, G, nrows, nslots, d_nact);
   return MVO_OK;
 }
 
@@ -1041,16 +1155,17 @@ int orb_detect_enqueue(mvo_ctx* ctx, int w, int h, int nslots, hipEvent_t before
   return MVO_OK;
 }
 
-static void orb_blur_enqueue(mvo_ctx* ctx, const OrbGeom& G, int nslots) {
+static void orb_blur_enqueue(mvo_ctx* ctx, const OrbGeom& G, int nslots, const int* d_nact = nullptr) {
   OrbState* o = ctx->orb;
-  BlurTaps T;
+  BlurArgs A;
   static const int k0[7] = {18, 34, 49, 55, 49, 34, 18};
   static const int k1[7] = {18, 34, 48, 56, 48, 34, 18};
-  for (int i = 0; i < 7; i++) T.k[i] = ctx->cfg.orb_blur_mode ? k1[i] : k0[i];
+  for (int i = 0; i < 7; i++) A.T.k[i] = ctx->cfg.orb_blur_mode ? k1[i] : k0[i];
+  A.pyr = o->d_pyr; A.out = o->d_blur; A.slot_stride = G.slot_stride; A.nact = d_nact;
   for (int l = 0; l < G.nlevels; l++) {
-    TileGrid tg{(G.w[l] + BL_W - 1) / BL_W, (G.h[l] + BL_H - 1) / BL_H, nslots};
-    hipLaunchKernelGGL(blur7_kernel, dim3(xcd_grid_blocks(tg)), dim3(256), 0, ctx->stream, o->d_pyr, o->d_blur, G.slot_stride, G.off[l],
-                       G.w[l], G.h[l], G.pitch[l], T, tg);
+    A.off = G.off[l]; A.w = G.w[l]; A.h = G.h[l]; A.pitch = G.pitch[l];
+    A.tg = TileGrid{(G.w[l] + BL_W - 1) / BL_W, (G.h[l] + BL_H - 1) / BL_H, nslots};
+    hipLaunchKernelGGL(blur7_kernel, dim3(d_nact ? persist_grid(xcd_grid_blocks(A.tg)) : xcd_grid_blocks(A.tg)), dim3(256), 0, ctx->stream, A);
   }
 }
 
@@ -1067,7 +1182,7 @@ int orb_select(mvo_ctx* ctx, int w, int h, int nslots, bool describe, std::vecto
     // OpenCV's two retainBest passes per level (2*quota by FAST score, quota by Harris), in libstdc++'s element order;
     // the Harris responses of the first pass's survivors are computed in between, inside the same kernel
     ProfScope ps(ctx, "orb_select");
-    int rc = orb_select_device(ctx, G, nslots);
+    int rc = orb_select_device(ctx, G, nslots, nullptr);
     if (rc) return rc;
   }
   MVO_HIP(hipMemcpyAsync(h_kpb, o->d_kp_base, (size_t)(nslots + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1091,18 +1206,47 @@ int orb_describe_enqueue(mvo_ctx* ctx, int w, int h, int nslots, bool describe, 
   if (nsel == 0) return MVO_OK;
   {
     ProfScope ps(ctx, "orb_describe");
+    const int* nul = nullptr;
     hipLaunchKernelGGL(ic_angle_kernel, dim3((nsel + 7) / 8), dim3(256), 0, st, o->d_pyr, G, o->d_sel, nsel, o->d_cx, o->d_cy,
-                       o->d_cl, o->d_cslot, o->d_ch, o->d_icmask, o->d_kp);
-    if (describe)
+                       o->d_cl, o->d_cslot, o->d_ch, o->d_icmask, o->d_kp, nul, nul);
+    if (describe) {
       hipLaunchKernelGGL(brief_rec_kernel, dim3((nsel + 255) / 256), dim3(256), 0, st, G, o->d_sel, nsel, o->d_cl, o->d_cslot, o->d_kp,
-                         (BriefRec*)o->d_brec);
+                         (BriefRec*)o->d_brec, nul, nul);
       hipLaunchKernelGGL(brief_kernel, dim3((nsel + 7) / 8), dim3(256), 0, st, o->d_blur,
-                         (const BriefRec*)o->d_brec, nsel, o->d_pattern, o->d_desc);
+                         (const BriefRec*)o->d_brec, nsel, o->d_pattern, o->d_desc, nul, nul);
+    }
   }
   if (to_host) {
     if (describe) MVO_HIP(hipMemcpyAsync(o->h_desc, o->d_desc, (size_t)nsel * 32, hipMemcpyDeviceToHost, st));
     MVO_HIP(hipMemcpyAsync(o->h_kp, o->d_kp, (size_t)nsel * sizeof(mvo_keypoint), hipMemcpyDeviceToHost, st));
     MVO_HIP(hipStreamSynchronize(st));
+  }
+  return MVO_OK;
+}
+
+// Device-driven detect + describe of the first *d_nact slots of the ORB pyramid (level 0 resident), for the frame-batch
+// tracker: every launch is sized for `max_slots` on the host and reads the real counts on the device, nothing waits for
+// the host.  Outputs: d_kp / d_desc (dense), d_kp_base[0 .. *d_nact].  Capacity overruns are clamped on the device; the
+// caller checks d_slot_base[*d_nact] / d_kp_base[*d_nact] against cand_cap / kp_cap where it reports results.
+int orb_run_device(mvo_ctx* ctx, int w, int h, int max_slots, const int* d_nact) {
+  OrbState* o = ctx->orb;
+  hipStream_t st = ctx->stream;
+  OrbGeom G;
+  orb_geom_for(ctx, w, h, G);
+  int rc;
+  { ProfScope ps(ctx, "orb_detect"); rc = orb_detect_device(ctx, G, max_slots, nullptr, d_nact); }
+  if (rc) return rc;
+  { ProfScope ps(ctx, "orb_select"); if ((rc = orb_select_device(ctx, G, max_slots, d_nact))) return rc; }
+  { ProfScope ps(ctx, "orb_blur"); orb_blur_enqueue(ctx, G, max_slots, d_nact); }
+  {
+    ProfScope ps(ctx, "orb_describe");
+    const int cap = o->kp_cap;
+    hipLaunchKernelGGL(ic_angle_kernel, dim3(persist_grid((cap + 7) / 8)), dim3(256), 0, st, o->d_pyr, G, o->d_sel, cap, o->d_cx, o->d_cy,
+                       o->d_cl, o->d_cslot, o->d_ch, o->d_icmask, o->d_kp, (const int*)o->d_kp_base, d_nact);
+    hipLaunchKernelGGL(brief_rec_kernel, dim3(persist_grid((cap + 255) / 256)), dim3(256), 0, st, G, o->d_sel, cap, o->d_cl, o->d_cslot,
+                       o->d_kp, (BriefRec*)o->d_brec, (const int*)o->d_kp_base, d_nact);
+    hipLaunchKernelGGL(brief_kernel, dim3(persist_grid((cap + 7) / 8)), dim3(256), 0, st, o->d_blur, (const BriefRec*)o->d_brec, cap,
+                       o->d_pattern, o->d_desc, (const int*)o->d_kp_base, d_nact);
   }
   return MVO_OK;
 }
@@ -1168,8 +1312,8 @@ extern "C" int mvo_fast9_nms(mvo_ctx* ctx, const uint8_t* img, int w, int h, int
   fast_nms_launch(ctx, G, 0, 1, threshold, 3);
   int nrows = G.row0[1];
   hipLaunchKernelGGL(scan_rows_kernel, dim3(1), dim3(1024), 0, st, o->d_row_cnt, o->d_row_off, G, o->max_rows, o->d_lvl_cnt,
-                     o->d_slot_tot);
-  hipLaunchKernelGGL(scan_slots_kernel, dim3(1), dim3(64), 0, st, o->d_slot_tot, o->d_slot_base, 1);
+                     o->d_slot_tot, (const int*)nullptr);
+  hipLaunchKernelGGL(scan_slots_kernel, dim3(1), dim3(64), 0, st, o->d_slot_tot, o->d_slot_base, 1, (const int*)nullptr);
   nms_rows_launch(ctx, G, nrows, 1);
   int* hn = (int*)ctx->h_pin;
   MVO_HIP(hipMemcpyAsync(hn, o->d_slot_tot, sizeof(int), hipMemcpyDeviceToHost, st));

@@ -259,6 +259,7 @@ struct OrbSelArgs {
   int nlevels;
   int quota[MVO_ORB_LEVELS];
   int cand_cap;
+  const int* nact;     // optional device count of active slots
 };
 
 // Levels with at most RB_LDS_CAP candidates (at 720p: all of them, level 0 has ~2-3 k) keep the (response, index) array
@@ -269,6 +270,7 @@ __global__ __launch_bounds__(RB_T) void orb_select_kernel(OrbSelArgs A) {
   __shared__ RbShared S;
   __shared__ uint2 s_a[RB_LDS_CAP];
   const int slot = blockIdx.y, l = blockIdx.x, tid = threadIdx.x;
+  if (A.nact && slot >= *A.nact) return;   // block-uniform
   int off = A.slot_base[slot];
   for (int k = 0; k < l; k++) off += A.lvl_cnt[slot * MVO_ORB_LEVELS + k];
   int cnt = A.lvl_cnt[slot * MVO_ORB_LEVELS + l];
@@ -300,10 +302,12 @@ __global__ __launch_bounds__(RB_T) void orb_select_kernel(OrbSelArgs A) {
 
 // kp_base[s] = sum of kept counts of the slots before s: one block, a chunk of 256 slots per pass (a slot per thread,
 // LDS Hillis-Steele scan, running carry)
-__global__ __launch_bounds__(256) void orb_sel_scan_kernel(const int* __restrict__ kept, int nslots, int nlevels, int* __restrict__ kp_base) {
+__global__ __launch_bounds__(256) void orb_sel_scan_kernel(const int* __restrict__ kept, int nslots, int nlevels, int* __restrict__ kp_base,
+                                                           const int* __restrict__ nact) {
   __shared__ int s_scan[2][256];
   __shared__ int s_carry;
   const int tid = threadIdx.x;
+  if (nact) nslots = min(max(*nact, 0), nslots);
   if (tid == 0) s_carry = 0;
   __syncthreads();
   for (int s0 = 0; s0 < nslots; s0 += 256) {
@@ -332,8 +336,10 @@ __global__ __launch_bounds__(256) void orb_sel_scan_kernel(const int* __restrict
 // dense selection list: slot-major, levels in order, each level in retainBest's order
 __global__ __launch_bounds__(256) void orb_sel_gather_kernel(const uint2* __restrict__ wk, const int* __restrict__ lvl_cnt,
                                                              const int* __restrict__ slot_base, const int* __restrict__ kept,
-                                                             const int* __restrict__ kp_base, int kp_cap, int* __restrict__ sel) {
+                                                             const int* __restrict__ kp_base, int kp_cap, int* __restrict__ sel,
+                                                             const int* __restrict__ nact) {
   const int slot = blockIdx.y, l = blockIdx.x;
+  if (nact && slot >= *nact) return;
   int off = slot_base[slot], dst = kp_base[slot];
   for (int k = 0; k < l; k++) { off += lvl_cnt[slot * MVO_ORB_LEVELS + k]; dst += kept[slot * MVO_ORB_LEVELS + k]; }
   const int m = kept[slot * MVO_ORB_LEVELS + l];
@@ -342,9 +348,10 @@ __global__ __launch_bounds__(256) void orb_sel_gather_kernel(const uint2* __rest
 }
 
 // Enqueue selection for `nslots` slots on ctx->stream; d_kp_base / d_sel are valid afterwards (device side).
-int orb_select_device(mvo_ctx* ctx, const OrbGeom& G, int nslots) {
+int orb_select_device(mvo_ctx* ctx, const OrbGeom& G, int nslots, const int* d_nact) {
   OrbState* o = ctx->orb;
   OrbSelArgs A;
+  A.nact = d_nact;
   A.cs = o->d_cs; A.ch = o->d_ch; A.lvl_cnt = o->d_lvl_cnt; A.slot_base = o->d_slot_base;
   A.pyr = o->d_pyr; A.slot_stride = G.slot_stride; A.cx = o->d_cx; A.cy = o->d_cy;
   for (int l = 0; l < MVO_ORB_LEVELS; l++) { A.lvl_off[l] = G.off[l]; A.lvl_pitch[l] = G.pitch[l]; }
@@ -353,9 +360,9 @@ int orb_select_device(mvo_ctx* ctx, const OrbGeom& G, int nslots) {
   for (int l = 0; l < MVO_ORB_LEVELS; l++) A.quota[l] = G.quota[l];
   A.cand_cap = o->cand_cap;
   hipLaunchKernelGGL(orb_select_kernel, dim3(G.nlevels, nslots), dim3(RB_T), 0, ctx->stream, A);
-  hipLaunchKernelGGL(orb_sel_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, o->d_kept, nslots, G.nlevels, o->d_kp_base);
+  hipLaunchKernelGGL(orb_sel_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, o->d_kept, nslots, G.nlevels, o->d_kp_base, d_nact);
   hipLaunchKernelGGL(orb_sel_gather_kernel, dim3(G.nlevels, nslots), dim3(256), 0, ctx->stream, o->d_wk, o->d_lvl_cnt, o->d_slot_base,
-                     o->d_kept, o->d_kp_base, o->kp_cap, o->d_sel);
+                     o->d_kept, o->d_kp_base, o->kp_cap, o->d_sel, d_nact);
   return MVO_OK;
 }
 

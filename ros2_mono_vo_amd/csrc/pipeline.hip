@@ -90,40 +90,7 @@ extern "C" int mvo_profile_reset(mvo_ctx* ctx) {
 // ---------------------------------------------------------------------------------------------------
 // pipeline state
 // ---------------------------------------------------------------------------------------------------
-struct PipeState {
-  int ring = 0;
-  int w = 0, h = 0, pitch = 0;  // geometry of the frames in the ring (fixed by the first preload)
-  size_t frame_bytes = 0;       // one slot's frame
-  u8* d_ring = nullptr;         // [ring][B][h][pitch]
-  float* d_lm = nullptr;        // [B][maxpts][3] landmark of each tracked point
-  float* d_kf_pts = nullptr;    // [B][maxpts][2] last key-frame position of each tracked point
-  float* d_cur_pts = nullptr;   // compacted survivors of LK
-  float* d_cur_lm = nullptr;
-  float* d_cur_kf = nullptr;
-  int* d_ncur = nullptr;        // [B]
-  float* d_kp_xy = nullptr;     // [B][maxpts][2] key-point positions of the current frame (match train side)
-  float* d_kfkp_xy = nullptr;   // [B][maxpts][2] key-point positions of the last key-frame (match query side)
-  int* h_ints = nullptr;        // pinned scratch
-  double K[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-  double dist[5] = {0, 0, 0, 0, 0};
-  bool seeded = false;
-  // landmark hand-over (device-resident Frame/KeyFrame bookkeeping, src/tracker.cpp:193-234)
-  u8* d_kf_has = nullptr;     // [B][maxpts] key-frame observation has a landmark
-  float* d_kf_lm = nullptr;   // [B][maxpts][3]
-  u8* d_cur_has = nullptr;
-  float* d_cur_lmk = nullptr; // [B][maxpts][3]
-  int* d_winner = nullptr;    // [B][maxpts] last valid match per current key-point
-  float* d_tri = nullptr;     // [B][maxpts][3] triangulated matches
-  u8* d_tri_ok = nullptr;     // [B][maxpts]
-  double* d_kf_pose = nullptr;  // [B][8] T_cw of the last key-frame (rvec, tvec)
-  int* d_ntri = nullptr;      // [B]
-  // side streams: the latency-bound RANSAC chains run beside ORB (they only depend on the LK survivors)
-  // s_lk carries pyramid + LK + filter (high priority: the RANSAC chains hang off it), main stream carries ORB.
-  hipStream_t s_lk = nullptr, s_pnp = nullptr, s_hf = nullptr;
-  hipEvent_t ev_frame = nullptr, ev_lktrack = nullptr, ev_lk = nullptr, ev_pnp = nullptr, ev_hf = nullptr;
-  int trk_max_n = 0;  // host-side bound on the per-slot track count (grid sizing)
-  int kf_max_n = 0;   // host-side bound on the key-frame descriptor count
-};
+// struct PipeState: mvo_internal.h (shared with track.hip)
 
 int pipe_state_create(mvo_ctx* ctx) {
   PipeState* p = new PipeState();
@@ -176,6 +143,7 @@ int pipe_state_create(mvo_ctx* ctx) {
 void pipe_state_destroy(mvo_ctx* ctx) {
   PipeState* p = ctx->pipe;
   if (p) {
+    trk_destroy(ctx);
     void* dev[] = {p->d_ring, p->d_lm, p->d_kf_pts, p->d_cur_pts, p->d_cur_lm, p->d_cur_kf, p->d_ncur, p->d_kp_xy, p->d_kfkp_xy,
                    p->d_kf_has, p->d_kf_lm, p->d_cur_has, p->d_cur_lmk, p->d_winner, p->d_tri, p->d_tri_ok, p->d_kf_pose, p->d_ntri};
     for (void* q : dev) (void)hipFree(q);
@@ -257,6 +225,12 @@ __global__ __launch_bounds__(1024) void lk_filter_compact_kernel(const float* __
     __syncthreads();
   }
   if (threadIdx.x == 0) o_n[slot] = s_base;
+}
+
+void lk_filter_compact_launch(mvo_ctx* ctx, hipStream_t st) {
+  PipeState* p = ctx->pipe;
+  hipLaunchKernelGGL(lk_filter_compact_kernel, dim3(ctx->B), dim3(1024), 0, st, ctx->d_next_pts, ctx->d_status, ctx->d_err, ctx->d_npts,
+                     p->d_lm, p->d_kf_pts, ctx->cfg.tracking_error_thresh, ctx->maxpts, p->d_cur_pts, p->d_cur_lm, p->d_cur_kf, p->d_ncur);
 }
 
 // dense ORB output (all slots back to back) -> per-slot matcher / track layout
@@ -450,7 +424,7 @@ extern "C" int mvo_batch_seed(mvo_ctx* ctx, int frame_idx, int* n_keypoints) {
   if (n_keypoints)
     for (int s = 0; s < ctx->B; s++) n_keypoints[s] = base[s + 1] - base[s];
   p->seeded = true;
-  return MVO_OK;
+  return trk_reset(ctx);   // per-stream tracker state: TRACKING, tracking_count_from_keyframe_ = 0
 }
 
 extern "C" int mvo_batch_get_tracks(mvo_ctx* ctx, int slot, float* pts, int cap, int* n) {

@@ -1,0 +1,698 @@
+// csrc/track.hip — frame-batch mode as B x Tracker::update: every camera stream (slot) carries its own tracker
+// state on the device and takes its own branch of the reference's per-frame step (src/tracker.cpp:274-333):
+//
+//   LOST is terminal                                                  src/tracker.cpp:277-279
+//   LK + status/err filter                                            :58-90, :289
+//   fewer than min_tracked_points survivors -> LOST, no pose          :292-296
+//   solvePnPRansac + Rodrigues -> pose                                :300-316
+//   ++tracking_count_from_keyframe; should_add_keyframe               :318-319, :118-136, :92-116
+//     -> has_parallax (findHomography + findFundamentalMat scores)    :320, :237-268
+//       -> add_new_keyframe (ORB, match, triangulate, landmarks)      :322, :182-235
+//   prev_frame_ = new_frame                                           :331
+//
+// The step is DEVICE DRIVEN: the per-slot decisions are taken by small policy kernels, the key-frame branch runs over
+// a compacted device-resident list of the slots that take it, and every launch is sized on the host for the worst case
+// and reads the real counts on the device (strided loops / early exits).  Nothing waits for the host between the first
+// and the last launch, so a step is enqueued asynchronously (mvo_batch_track_async) and several contexts interleave on
+// one GPU: the one-wavefront-per-stream RANSAC chains of one context run beside the wide LK / ORB kernels of another.
+// Ingest is asynchronous as well: mvo_batch_upload_async copies pinned host frames into the device ring on a dedicated
+// stream while the previous step computes.
+#include "mvo_internal.h"
+
+#include <cfloat>
+#include <cmath>
+
+struct TrackState {
+  int* d_state = nullptr;      // [B] MVO_TRACK_*
+  int* d_count = nullptr;      // [B] tracking_count_from_keyframe_
+  int* d_flags = nullptr;      // [B] MVO_STEP_* of the running step
+  int* d_n_pnp = nullptr;      // [B] correspondences fed to PnP (0 = slot sits the stage out)
+  int* d_n_hf = nullptr;       // [B] correspondences fed to H / F (0 = no key-frame test this frame)
+  int* d_kf_list = nullptr;    // [B] slots that add a key-frame this step, ascending
+  int* d_nkf = nullptr;        // [1]
+  int* d_pt_base = nullptr;    // [B+1] LK work list: first item of each slot
+  int* d_work_slot = nullptr;  // [B*maxpts] LK work list: slot of each item
+  int* d_work_ctr = nullptr;   // [1]
+  int* d_err = nullptr;        // [1] capacity flags raised on the device
+  u8* d_mask_f = nullptr;      // [B][maxpts] F consensus mask (H uses geom->d_mask2)
+  double* d_model_f = nullptr; // [B][16]
+  int* d_result_f = nullptr;   // [B][8]
+  mvo_step_result* d_res = nullptr;  // [B]
+  mvo_step_result* h_res = nullptr;  // pinned
+  int* h_err = nullptr;              // pinned [1]
+  int policy = 0;              // 0: the reference's key-frame policy, 1: key-frame branch on every tracked frame (worst case)
+  bool pending = false;
+  hipEvent_t ev_done = nullptr;
+};
+
+#define TRK_ERR_KEYPOINTS 1   // a slot's key-points exceeded max_points (clamped)
+#define TRK_ERR_CAND 2        // FAST candidates exceeded the candidate capacity (clamped)
+#define TRK_ERR_KPCAP 4       // dense key-point capacity exceeded (clamped)
+
+// ---------------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------------
+// LK work list: exclusive scan of the track counts of the slots that are still tracking (one workgroup).
+__global__ __launch_bounds__(1024) void trk_worklist_scan_kernel(const int* __restrict__ state, int* __restrict__ npts, int B, int maxpts,
+                                                                 int* __restrict__ pt_base, int* __restrict__ work_ctr,
+                                                                 int* __restrict__ flags, mvo_step_result* __restrict__ res) {
+  __shared__ int s_w[16];
+  __shared__ int s_run;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) { s_run = 0; *work_ctr = 0; }
+  __syncthreads();
+  for (int s0 = 0; s0 < B; s0 += 1024) {
+    const int s = s0 + threadIdx.x;
+    int v = 0;
+    if (s < B) {
+      v = state[s] == MVO_TRACK_TRACKING ? min(max(npts[s], 0), maxpts) : 0;
+      npts[s] = v;        // a LOST / ABORTED stream feeds nothing to LK (Tracker::update returns at once)
+      flags[s] = 0;
+      mvo_step_result z;
+      memset(&z, 0, sizeof(z));
+      z.n_prev = v;
+      res[s] = z;
+    }
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      int t = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += t;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    int off = s_run;
+    for (int k = 0; k < wave; k++) off += s_w[k];
+    if (s < B) pt_base[s] = off + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int k = 0; k < 16; k++) t += s_w[k];
+      s_run += t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) pt_base[B] = s_run;
+}
+
+__global__ __launch_bounds__(256) void trk_worklist_expand_kernel(const int* __restrict__ pt_base, int* __restrict__ work_slot) {
+  const int s = blockIdx.x;
+  const int b = pt_base[s], e = pt_base[s + 1];
+  for (int i = b + threadIdx.x; i < e; i += 256) work_slot[i] = s;
+}
+
+// LK level 0 of the "cur" pyramid set <- ring frame (all slots; 16 B per lane)
+__global__ __launch_bounds__(256) void trk_ring_to_lk0_kernel(const u8* __restrict__ ring, size_t ring_slot_stride, int pitch, int h,
+                                                              u8* __restrict__ lk0, size_t lk_slot_stride) {
+  const int slot = blockIdx.y;
+  const size_t n16 = (size_t)pitch * h / 16;
+  const uint4* s = (const uint4*)(ring + (size_t)slot * ring_slot_stride);
+  uint4* a = (uint4*)(lk0 + (size_t)slot * lk_slot_stride);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) a[i] = s[i];
+}
+
+// After the status/err filter: min_tracked_points -> LOST (src/tracker.cpp:292-296); the others go on to PnP.
+__global__ __launch_bounds__(256) void trk_policy_lost_kernel(int* __restrict__ state, const int* __restrict__ ncur, int B,
+                                                              long long min_tracked, int* __restrict__ n_pnp, int* __restrict__ flags,
+                                                              mvo_step_result* __restrict__ res) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= B) return;
+  int n = 0;
+  if (state[s] == MVO_TRACK_TRACKING) {
+    const int nc = ncur[s];
+    res[s].n_tracked = nc;
+    if ((long long)nc < min_tracked) { state[s] = MVO_TRACK_LOST; flags[s] |= MVO_STEP_LOST_NOW; }
+    else n = nc;
+  }
+  n_pnp[s] = n;
+}
+
+__device__ inline void trk_rodrigues(const double r_[3], double R[9]) {   // calibration.cpp cvRodrigues2, vector -> matrix
+  double rx = r_[0], ry = r_[1], rz = r_[2];
+  const double theta = sqrt(rx * rx + ry * ry + rz * rz);
+  if (theta < DBL_EPSILON) {
+    for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1 : 0;
+    return;
+  }
+  const double c = cos(theta), s = sin(theta), c1 = 1. - c, it = 1. / theta;
+  rx *= it; ry *= it; rz *= it;
+  const double rrt[9] = {rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz};
+  const double r_x[9] = {0, -rz, ry, rz, 0, -rx, -ry, rx, 0};
+  for (int k = 0; k < 9; k++) R[k] = c * ((k % 4 == 0) ? 1. : 0.) + c1 * rrt[k] + s * r_x[k];
+}
+
+// After PnP: pose, ++tracking_count_from_keyframe_, should_add_keyframe (src/tracker.cpp:318-319, 118-136, 92-116).
+// The reference does not look at solvePnPRansac's return value: on failure rvec stays empty and cv::Rodrigues throws out
+// of image_callback.  Here the stream goes to MVO_TRACK_ABORTED (terminal, no pose) instead of taking the process down.
+__global__ __launch_bounds__(256) void trk_policy_keyframe_kernel(int* __restrict__ state, int* __restrict__ count, int B,
+                                                                  const int* __restrict__ n_pnp, const int* __restrict__ pnp_result,
+                                                                  const double* __restrict__ pose, const double* __restrict__ kf_pose,
+                                                                  long long min_obs, long long max_after, double max_trans,
+                                                                  double max_rot, int policy, int* __restrict__ n_hf,
+                                                                  int* __restrict__ flags, mvo_step_result* __restrict__ res) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= B) return;
+  int nhf = 0;
+  const int n = n_pnp[s];
+  if (n > 0 && state[s] == MVO_TRACK_TRACKING) {
+    const int ok = pnp_result[8 * s] && pnp_result[8 * s + 6];
+    res[s].pnp_ok = ok;
+    res[s].n_pnp_inliers = pnp_result[8 * s + 5];
+    if (!ok) {
+      state[s] = MVO_TRACK_ABORTED;
+      flags[s] |= MVO_STEP_ABORTED_NOW;
+    } else {
+      const double* p = pose + 8 * s;
+      for (int k = 0; k < 3; k++) { res[s].rvec[k] = p[k]; res[s].tvec[k] = p[3 + k]; }
+      flags[s] |= MVO_STEP_POSE;
+      const int c = count[s] + 1;
+      count[s] = c;
+      bool add = (long long)n < min_obs || (long long)c > max_after;
+      if (!add) {
+        // has_significant_motion: relative pose kf_wc^-1 * cur_wc = T_kf_cw * T_cur_cw^-1
+        double Rk[9], Rc[9];
+        trk_rodrigues(kf_pose + 8 * s, Rk);
+        trk_rodrigues(p, Rc);
+        const double* tk = kf_pose + 8 * s + 3;
+        double Rr[9];
+        for (int i = 0; i < 3; i++)
+          for (int j = 0; j < 3; j++) Rr[3 * i + j] = Rk[3 * i] * Rc[3 * j] + Rk[3 * i + 1] * Rc[3 * j + 1] + Rk[3 * i + 2] * Rc[3 * j + 2];
+        double tr[3];
+        for (int i = 0; i < 3; i++) tr[i] = tk[i] - (Rr[3 * i] * p[3] + Rr[3 * i + 1] * p[4] + Rr[3 * i + 2] * p[5]);
+        const double translation = sqrt(tr[0] * tr[0] + tr[1] * tr[1] + tr[2] * tr[2]);
+        if (translation > max_trans) add = true;
+        else {
+          const double rotation = acos((Rr[0] + Rr[4] + Rr[8] - 1.0) / 2.0);   // NaN outside [-1, 1]: the test below is false
+          add = rotation > max_rot;
+        }
+      }
+      if (policy == 1) add = true;
+      if (add) { nhf = n; flags[s] |= MVO_STEP_KF_CHECKED; }
+    }
+  }
+  n_hf[s] = nhf;
+}
+
+// After H / F: has_parallax (src/tracker.cpp:253-265, divisions unguarded as there) and the ordered list of the slots
+// that add a key-frame.  One workgroup.
+__global__ __launch_bounds__(1024) void trk_policy_parallax_kernel(const int* __restrict__ n_hf, const int* __restrict__ res_h,
+                                                                   const int* __restrict__ res_f, int B, double f_inlier_thresh,
+                                                                   double model_score_thresh, int policy, int* __restrict__ flags,
+                                                                   mvo_step_result* __restrict__ res, int* __restrict__ kf_list,
+                                                                   int* __restrict__ nkf) {
+  __shared__ int s_wave[16];
+  __shared__ int s_base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  for (int s0 = 0; s0 < B; s0 += 1024) {
+    const int s = s0 + threadIdx.x;
+    bool kf = false;
+    if (s < B && n_hf[s] > 0) {
+      const int sh = res_h[8 * s] ? res_h[8 * s + 1] : 0;
+      const int sf = res_f[8 * s] ? res_f[8 * s + 1] : 0;
+      res[s].score_h = sh; res[s].score_f = sf;
+      kf = true;
+      if ((double)sf / (double)n_hf[s] < f_inlier_thresh) kf = false;
+      else {
+        const double model_score = (double)sh / (double)sf;   // inf / NaN as in the reference
+        if (model_score > model_score_thresh) kf = false;
+      }
+      if (policy == 1) kf = true;
+      if (kf) flags[s] |= MVO_STEP_KEYFRAME;
+    }
+    const unsigned long long m = __ballot(kf);
+    const int pre = __popcll(m & ((1ull << lane) - 1));
+    if (lane == 0) s_wave[wave] = __popcll(m);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wave; w++) off += s_wave[w];
+    if (kf) kf_list[off + pre] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int w = 0; w < 16; w++) t += s_wave[w];
+      s_base += t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *nkf = s_base;
+}
+
+// ORB level 0 of compact ORB slot j <- LK "cur" level 0 of stream slot kf_list[j] (same image, same pitch)
+__global__ __launch_bounds__(256) void trk_gather_orb0_kernel(const u8* __restrict__ lk0, size_t lk_slot_stride, int pitch, int h,
+                                                              u8* __restrict__ orb0, size_t orb_slot_stride,
+                                                              const int* __restrict__ kf_list, const int* __restrict__ nkf, int chunks) {
+  const int n = *nkf;
+  const size_t n16 = (size_t)pitch * h / 16;
+  const unsigned total = (unsigned)n * (unsigned)chunks;
+  for (unsigned wi = blockIdx.x; wi < total; wi += gridDim.x) {
+    const int j = (int)(wi / (unsigned)chunks), c = (int)(wi - (unsigned)j * (unsigned)chunks);
+    const uint4* s = (const uint4*)(lk0 + (size_t)kf_list[j] * lk_slot_stride);
+    uint4* d = (uint4*)(orb0 + (size_t)j * orb_slot_stride);
+    for (size_t i = (size_t)c * 256 + threadIdx.x; i < n16; i += (size_t)chunks * 256) d[i] = s[i];
+  }
+}
+
+// dense ORB output of compact slot j -> matcher train side / key-point positions of stream slot kf_list[j]
+__global__ __launch_bounds__(256) void trk_scatter_kp_kernel(const mvo_keypoint* __restrict__ kp, const u8* __restrict__ desc,
+                                                             const int* __restrict__ kp_base, const int* __restrict__ kf_list,
+                                                             const int* __restrict__ nkf, int maxpts, int kp_cap, u8* __restrict__ t_desc,
+                                                             int* __restrict__ t_n, float* __restrict__ kp_xy, int* __restrict__ err,
+                                                             mvo_step_result* __restrict__ res) {
+  const int j = blockIdx.y;
+  if (j >= *nkf) return;
+  const int slot = kf_list[j];
+  const int b0 = min(kp_base[j], kp_cap);
+  int n = min(kp_base[j + 1], kp_cap) - b0;
+  if (n > maxpts) { n = maxpts; if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(err, TRK_ERR_KEYPOINTS); }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { t_n[slot] = n; res[slot].n_keypoints = n; }
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n * 8; i += gridDim.x * 256) {
+    const int k = i >> 3, q = i & 7;
+    ((unsigned*)t_desc)[((size_t)slot * maxpts + k) * 8 + q] = ((const unsigned*)desc)[(size_t)(b0 + k) * 8 + q];
+    if (q == 0) {
+      kp_xy[2 * ((size_t)slot * maxpts + k)] = kp[b0 + k].x;
+      kp_xy[2 * ((size_t)slot * maxpts + k) + 1] = kp[b0 + k].y;
+    }
+  }
+}
+
+// capacity checks that the host did on counts it had waited for
+__global__ void trk_orb_capcheck_kernel(const int* __restrict__ slot_base, const int* __restrict__ kp_base, const int* __restrict__ nkf,
+                                        int cand_cap, int kp_cap, int* __restrict__ err) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const int n = max(*nkf, 0);
+    if (slot_base[n] > cand_cap) atomicOr(err, TRK_ERR_CAND);
+    if (kp_base[n] > kp_cap) atomicOr(err, TRK_ERR_KPCAP);
+  }
+}
+
+// ---- landmark hand-over of Tracker::add_new_keyframe (src/tracker.cpp:211-227) over the key-frame list ------------
+// Matches are visited in order in the reference, so when several share a train index the LAST valid one decides that
+// key-point's landmark: winner[t] = max valid match index (phase 1), then per key-point take the winner (phase 2).
+__global__ __launch_bounds__(256) void trk_winner_clear_kernel(const int* __restrict__ kf_list, const int* __restrict__ nkf,
+                                                               const int* __restrict__ n_kp, int cap, int* __restrict__ winner) {
+  const int j = blockIdx.y;
+  if (j >= *nkf) return;
+  const int slot = kf_list[j];
+  const int n = min(max(n_kp[slot], 0), cap);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) winner[(size_t)slot * cap + i] = -1;
+}
+
+__global__ __launch_bounds__(256) void trk_winner_kernel(const mvo_match* __restrict__ matches, const int* __restrict__ n_matches,
+                                                         const u8* __restrict__ valid, int cap, const int* __restrict__ kf_list,
+                                                         const int* __restrict__ nkf, int* __restrict__ winner) {
+  const int j = blockIdx.y;
+  if (j >= *nkf) return;
+  const int slot = kf_list[j];
+  const int n = min(max(n_matches[slot], 0), cap);
+  const size_t b = (size_t)slot * cap;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+    if (valid[b + i]) atomicMax(&winner[b + matches[b + i].train_idx], i);
+}
+
+// Phase 2 + promotion of the new key-frame, one workgroup per list entry: landmarks of the current key-points, their
+// ordered compaction into the next frame's tracks (Frame::get_points_2d(WITH_LANDMARKS)), then current frame -> key-frame
+// (descriptors, positions, per-observation landmarks, pose) and tracking_count_from_keyframe_ = 0.
+__global__ __launch_bounds__(1024) void trk_assign_promote_kernel(const int* __restrict__ kf_list, const int* __restrict__ nkf,
+                                                                  const mvo_match* __restrict__ matches, const int* __restrict__ winner,
+                                                                  const int* __restrict__ n_kp, float* __restrict__ kp_xy,
+                                                                  u8* __restrict__ kf_has, float* __restrict__ kf_lm,
+                                                                  const float* __restrict__ tri, const u8* __restrict__ tri_ok,
+                                                                  const int* __restrict__ n_matches, int cap, u8* __restrict__ cur_has,
+                                                                  float* __restrict__ cur_lm, float* __restrict__ trk_xy,
+                                                                  float* __restrict__ trk_lm, float* __restrict__ trk_kf,
+                                                                  int* __restrict__ n_trk, float* __restrict__ kfkp_xy,
+                                                                  u8* __restrict__ q_desc, const u8* __restrict__ t_desc,
+                                                                  int* __restrict__ n_q, double* __restrict__ kf_pose,
+                                                                  const double* __restrict__ pose, int* __restrict__ count,
+                                                                  mvo_step_result* __restrict__ res) {
+  __shared__ int s_wave[16];
+  __shared__ int s_base;
+  __shared__ int s_tri;
+  if ((int)blockIdx.x >= *nkf) return;
+  const int slot = kf_list[blockIdx.x], lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = min(max(n_kp[slot], 0), cap);
+  const size_t b = (size_t)slot * cap;
+  if (threadIdx.x == 0) { s_base = 0; s_tri = 0; }
+  __syncthreads();
+  int tri_cnt = 0;
+  const int nm = min(max(n_matches[slot], 0), cap);
+  for (int i = threadIdx.x; i < nm; i += 1024) tri_cnt += tri_ok[b + i] ? 1 : 0;
+  if (tri_cnt) atomicAdd(&s_tri, tri_cnt);
+  for (int t0 = 0; t0 < n; t0 += 1024) {
+    const int t = t0 + threadIdx.x;
+    bool has = false;
+    float lx = 0, ly = 0, lz = 0;
+    if (t < n) {
+      const int wi = winner[b + t];
+      if (wi >= 0) {
+        const int q = matches[b + wi].query_idx;
+        has = true;
+        if (kf_has[b + q]) { lx = kf_lm[3 * (b + q)]; ly = kf_lm[3 * (b + q) + 1]; lz = kf_lm[3 * (b + q) + 2]; }
+        else { lx = tri[3 * (b + wi)]; ly = tri[3 * (b + wi) + 1]; lz = tri[3 * (b + wi) + 2]; }
+      }
+      cur_has[b + t] = has ? 1 : 0;
+      cur_lm[3 * (b + t)] = lx; cur_lm[3 * (b + t) + 1] = ly; cur_lm[3 * (b + t) + 2] = lz;
+    }
+    const unsigned long long m = __ballot(has);
+    const int pre = __popcll(m & ((1ull << lane) - 1));
+    if (lane == 0) s_wave[wave] = __popcll(m);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wave; w++) off += s_wave[w];
+    if (has) {
+      const size_t o = b + off + pre;
+      const float x = kp_xy[2 * (b + t)], y = kp_xy[2 * (b + t) + 1];
+      trk_xy[2 * o] = x; trk_xy[2 * o + 1] = y;
+      trk_kf[2 * o] = x; trk_kf[2 * o + 1] = y;
+      trk_lm[3 * o] = lx; trk_lm[3 * o + 1] = ly; trk_lm[3 * o + 2] = lz;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int tt = 0;
+      for (int w = 0; w < 16; w++) tt += s_wave[w];
+      s_base += tt;
+    }
+    __syncthreads();
+  }
+  // every read of the old key-frame's landmarks (kf_has / kf_lm) is done: the current frame becomes the key-frame
+  __syncthreads();
+  for (int t = threadIdx.x; t < n; t += 1024) {
+    kf_has[b + t] = cur_has[b + t];
+    kf_lm[3 * (b + t)] = cur_lm[3 * (b + t)]; kf_lm[3 * (b + t) + 1] = cur_lm[3 * (b + t) + 1]; kf_lm[3 * (b + t) + 2] = cur_lm[3 * (b + t) + 2];
+    kfkp_xy[2 * (b + t)] = kp_xy[2 * (b + t)]; kfkp_xy[2 * (b + t) + 1] = kp_xy[2 * (b + t) + 1];
+  }
+  {
+    const uint4* s = (const uint4*)(t_desc + b * 32);
+    uint4* d = (uint4*)(q_desc + b * 32);
+    for (int i = threadIdx.x; i < n * 2; i += 1024) d[i] = s[i];
+  }
+  if (threadIdx.x < 8) kf_pose[8 * slot + threadIdx.x] = pose[8 * slot + threadIdx.x];
+  if (threadIdx.x == 0) {
+    n_trk[slot] = s_base;
+    n_q[slot] = n;
+    count[slot] = 0;
+    res[slot].n_matches = nm;
+    res[slot].n_triangulated = s_tri;
+  }
+}
+
+// Slots that tracked but added no key-frame: the LK survivors are the next frame's observations (src/tracker.cpp:331);
+// then the result records of all slots.
+__global__ __launch_bounds__(256) void trk_finalize_kernel(const int* __restrict__ state, const int* __restrict__ count,
+                                                           const int* __restrict__ flags, const int* __restrict__ ncur, int maxpts,
+                                                           const float* __restrict__ cur_pts, const float* __restrict__ cur_lm,
+                                                           const float* __restrict__ cur_kf, float* __restrict__ trk_xy,
+                                                           float* __restrict__ trk_lm, float* __restrict__ trk_kf, int* __restrict__ npts,
+                                                           mvo_step_result* __restrict__ res) {
+  const int slot = blockIdx.x;
+  const int f = flags[slot], st = state[slot];
+  const size_t b = (size_t)slot * maxpts;
+  if (st == MVO_TRACK_TRACKING && (f & MVO_STEP_POSE) && !(f & MVO_STEP_KEYFRAME)) {
+    const int n = min(max(ncur[slot], 0), maxpts);
+    for (int i = threadIdx.x; i < 2 * n; i += 256) { trk_xy[2 * b + i] = cur_pts[2 * b + i]; trk_kf[2 * b + i] = cur_kf[2 * b + i]; }
+    for (int i = threadIdx.x; i < 3 * n; i += 256) trk_lm[3 * b + i] = cur_lm[3 * b + i];
+    if (threadIdx.x == 0) npts[slot] = n;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (st != MVO_TRACK_TRACKING) npts[slot] = 0;
+    res[slot].state = st;
+    res[slot].flags = f;
+    res[slot].tracking_count = count[slot];
+    res[slot].n_tracks = npts[slot];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// state
+// ---------------------------------------------------------------------------------------------------
+static int trk_create(mvo_ctx* ctx) {
+  PipeState* p = ctx->pipe;
+  if (p->trk) return MVO_OK;
+  TrackState* t = new TrackState();
+  p->trk = t;
+  const int B = ctx->B;
+  const size_t np = (size_t)B * ctx->maxpts;
+  MVO_HIP(hipMalloc(&t->d_state, B * sizeof(int)));
+  MVO_HIP(hipMalloc(&t->d_count, B * sizeof(int)));
+  MVO_HIP(hipMalloc(&t->d_flags, B * sizeof(int)));
+  MVO_HIP(hipMalloc(&t->d_n_pnp, B * sizeof(int)));
+  MVO_HIP(hipMalloc(&t->d_n_hf, B * sizeof(int)));
+  MVO_HIP(hipMalloc(&t->d_kf_list, B * sizeof(int)));
+  MVO_HIP(hipMalloc(&t->d_nkf, sizeof(int)));
+  MVO_HIP(hipMalloc(&t->d_pt_base, (B + 1) * sizeof(int)));
+  MVO_HIP(hipMalloc(&t->d_work_slot, np * sizeof(int)));
+  MVO_HIP(hipMalloc(&t->d_work_ctr, sizeof(int)));
+  MVO_HIP(hipMalloc(&t->d_err, sizeof(int)));
+  MVO_HIP(hipMalloc(&t->d_mask_f, np));
+  MVO_HIP(hipMalloc(&t->d_model_f, (size_t)B * 16 * sizeof(double)));
+  MVO_HIP(hipMalloc(&t->d_result_f, (size_t)B * 8 * sizeof(int)));
+  MVO_HIP(hipMalloc(&t->d_res, (size_t)B * sizeof(mvo_step_result)));
+  MVO_HIP(hipHostMalloc(&t->h_res, (size_t)B * sizeof(mvo_step_result), hipHostMallocDefault));
+  MVO_HIP(hipHostMalloc(&t->h_err, sizeof(int), hipHostMallocDefault));
+  MVO_HIP(hipEventCreateWithFlags(&t->ev_done, hipEventDisableTiming));
+  MVO_HIP(hipMemsetAsync(t->d_state, 0, B * sizeof(int), ctx->stream));
+  MVO_HIP(hipMemsetAsync(t->d_count, 0, B * sizeof(int), ctx->stream));
+  MVO_HIP(hipMemsetAsync(t->d_err, 0, sizeof(int), ctx->stream));
+  MVO_HIP(hipMemsetAsync(t->d_nkf, 0, sizeof(int), ctx->stream));
+  MVO_HIP(hipMemsetAsync(t->d_result_f, 0, (size_t)B * 8 * sizeof(int), ctx->stream));
+  return MVO_OK;
+}
+
+void trk_destroy(mvo_ctx* ctx) {
+  PipeState* p = ctx->pipe;
+  if (!p) return;
+  if (p->s_up) { (void)hipStreamSynchronize(p->s_up); (void)hipStreamDestroy(p->s_up); p->s_up = nullptr; }
+  for (auto e : p->ev_up) (void)hipEventDestroy(e);
+  for (auto e : p->ev_rd) (void)hipEventDestroy(e);
+  p->ev_up.clear(); p->ev_rd.clear();
+  TrackState* t = p->trk;
+  if (!t) return;
+  void* dev[] = {t->d_state, t->d_count, t->d_flags, t->d_n_pnp, t->d_n_hf, t->d_kf_list, t->d_nkf, t->d_pt_base, t->d_work_slot,
+                 t->d_work_ctr, t->d_err, t->d_mask_f, t->d_model_f, t->d_result_f, t->d_res};
+  for (void* q : dev) (void)hipFree(q);
+  if (t->h_res) (void)hipHostFree(t->h_res);
+  if (t->h_err) (void)hipHostFree(t->h_err);
+  if (t->ev_done) (void)hipEventDestroy(t->ev_done);
+  delete t;
+  p->trk = nullptr;
+}
+
+static int trk_ring_events(mvo_ctx* ctx) {
+  PipeState* p = ctx->pipe;
+  if (!p->ev_up.empty()) return MVO_OK;
+  MVO_HIP(hipStreamCreateWithFlags(&p->s_up, hipStreamNonBlocking));
+  p->ev_up.resize(p->ring); p->ev_rd.resize(p->ring);
+  p->up_pending.assign(p->ring, 0); p->rd_pending.assign(p->ring, 0);
+  for (int i = 0; i < p->ring; i++) {
+    MVO_HIP(hipEventCreateWithFlags(&p->ev_up[i], hipEventDisableTiming));
+    MVO_HIP(hipEventCreateWithFlags(&p->ev_rd[i], hipEventDisableTiming));
+  }
+  return MVO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// API
+// ---------------------------------------------------------------------------------------------------
+extern "C" int mvo_host_alloc(size_t bytes, void** out) {
+  if (!out || bytes == 0) return MVO_E_ARG;
+  return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? MVO_OK : MVO_E_HIP;
+}
+
+extern "C" int mvo_host_free(void* p) { return (!p || hipHostFree(p) == hipSuccess) ? MVO_OK : MVO_E_HIP; }
+
+extern "C" int mvo_batch_set_policy(mvo_ctx* ctx, int policy) {
+  if (!ctx || !ctx->pipe || ctx->pipe->ring <= 0 || (policy != 0 && policy != 1)) return MVO_E_ARG;
+  int rc = trk_create(ctx);
+  if (rc) return rc;
+  ctx->pipe->trk->policy = policy;
+  return MVO_OK;
+}
+
+// All B frames of ring entry `frame_idx` in one asynchronous copy on the upload stream.  `frames` holds B mono8 images,
+// `slot_stride` bytes apart, rows `stride` bytes apart; pinned memory (mvo_host_alloc / hipHostRegister) makes the copy
+// overlap the step that is running.  The copy waits for the step that last read this ring entry.
+extern "C" int mvo_batch_upload_async(mvo_ctx* ctx, int frame_idx, const uint8_t* frames, int w, int h, int stride, size_t slot_stride) {
+  if (!ctx || !ctx->pipe || !frames) return MVO_E_ARG;
+  PipeState* p = ctx->pipe;
+  if (p->ring <= 0 || frame_idx < 0 || frame_idx >= p->ring) return MVO_E_ARG;
+  if (w > ctx->maxw || h > ctx->maxh || w < 32 || h < 32 || stride < w || slot_stride < (size_t)stride * (h - 1) + w) return MVO_E_ARG;
+  if (p->w == 0) { p->w = w; p->h = h; p->pitch = align_up(w, 64); }
+  if (w != p->w || h != p->h) { ctx->set_error("all ring frames must share one size"); return MVO_E_ARG; }
+  int rc = trk_ring_events(ctx);
+  if (rc) return rc;
+  if (p->rd_pending[frame_idx]) { MVO_HIP(hipStreamWaitEvent(p->s_up, p->ev_rd[frame_idx], 0)); p->rd_pending[frame_idx] = 0; }
+  u8* dst = p->d_ring + (size_t)frame_idx * ctx->B * p->frame_bytes;
+  if (stride == p->pitch && slot_stride == p->frame_bytes) {
+    MVO_HIP(hipMemcpyAsync(dst, frames, p->frame_bytes * ctx->B, hipMemcpyHostToDevice, p->s_up));
+  } else if (slot_stride == (size_t)stride * h) {
+    // one 2-D copy: the B images are one tall image of B*h rows on the host; on the device the slots are frame_bytes
+    // = pitch * maxh apart, which equals pitch * h only when h == maxh
+    if ((size_t)p->pitch * h == p->frame_bytes) {
+      MVO_HIP(hipMemcpy2DAsync(dst, p->pitch, frames, stride, w, (size_t)h * ctx->B, hipMemcpyHostToDevice, p->s_up));
+    } else {
+      for (int s = 0; s < ctx->B; s++)
+        MVO_HIP(hipMemcpy2DAsync(dst + (size_t)s * p->frame_bytes, p->pitch, frames + (size_t)s * slot_stride, stride, w, h,
+                                 hipMemcpyHostToDevice, p->s_up));
+    }
+  } else {
+    for (int s = 0; s < ctx->B; s++)
+      MVO_HIP(hipMemcpy2DAsync(dst + (size_t)s * p->frame_bytes, p->pitch, frames + (size_t)s * slot_stride, stride, w, h,
+                               hipMemcpyHostToDevice, p->s_up));
+  }
+  MVO_HIP(hipEventRecord(p->ev_up[frame_idx], p->s_up));
+  p->up_pending[frame_idx] = 1;
+  return MVO_OK;
+}
+
+// Enqueue one tracker step of every slot on ring frame `frame_idx`; returns without waiting for the device.
+extern "C" int mvo_batch_track_async(mvo_ctx* ctx, int frame_idx) {
+  if (!ctx || !ctx->pipe) return MVO_E_ARG;
+  PipeState* p = ctx->pipe;
+  MatchState* m = ctx->match;
+  GeomState* g = ctx->geom;
+  OrbState* o = ctx->orb;
+  if (!p->seeded || frame_idx < 0 || frame_idx >= p->ring) { ctx->set_error("mvo_batch_track: not seeded / bad frame"); return MVO_E_ARG; }
+  int rc = trk_create(ctx);
+  if (rc) return rc;
+  TrackState* t = p->trk;
+  if (t->pending) { ctx->set_error("mvo_batch_track_async: the previous step has not been collected (mvo_batch_track_wait)"); return MVO_E_ARG; }
+  if ((rc = trk_ring_events(ctx))) return rc;
+  const int B = ctx->B, cap = ctx->maxpts;
+  hipStream_t st = ctx->stream;
+  const mvo_config& c = ctx->cfg;
+  LkLevels L = lk_levels(p->w, p->h, c.lk_win, c.lk_max_level);
+  const int prev_set = ctx->lk_cur, cur_set = ctx->lk_cur ^ 1;
+  const int nb = (B + 255) / 256;
+
+  if (p->up_pending[frame_idx]) { MVO_HIP(hipStreamWaitEvent(st, p->ev_up[frame_idx], 0)); p->up_pending[frame_idx] = 0; }
+  // ---- LK: frame -> "cur" pyramid; dense work list over the slots that are tracking ----------------------------------
+  {
+    ProfScope ps(ctx, "frame_fanout");
+    const u8* src = p->d_ring + (size_t)frame_idx * B * p->frame_bytes;
+    hipLaunchKernelGGL(trk_ring_to_lk0_kernel, dim3(64, B), dim3(256), 0, st, src, p->frame_bytes, p->pitch, p->h,
+                       ctx->lk_mem[cur_set] + ctx->lk_level_off[0], ctx->lk_slot_bytes);
+  }
+  MVO_HIP(hipEventRecord(p->ev_rd[frame_idx], st));   // the ring entry may be overwritten from here on
+  p->rd_pending[frame_idx] = 1;
+  { ProfScope ps(ctx, "lk_pyramid"); lk_build_pyramid(ctx, cur_set, L, B, st); }
+  {
+    ProfScope ps(ctx, "lk_track");
+    hipLaunchKernelGGL(trk_worklist_scan_kernel, dim3(1), dim3(1024), 0, st, t->d_state, ctx->d_npts, B, cap, t->d_pt_base, t->d_work_ctr,
+                       t->d_flags, t->d_res);
+    hipLaunchKernelGGL(trk_worklist_expand_kernel, dim3(B), dim3(256), 0, st, t->d_pt_base, t->d_work_slot);
+    lk_track_device(ctx, prev_set, cur_set, L, B, cap, st, t->d_work_slot, t->d_pt_base, t->d_work_ctr);
+  }
+  {
+    ProfScope ps(ctx, "lk_filter");
+    lk_filter_compact_launch(ctx, st);
+    hipLaunchKernelGGL(trk_policy_lost_kernel, dim3(nb), dim3(256), 0, st, t->d_state, p->d_ncur, B, (long long)c.min_tracked_points,
+                       t->d_n_pnp, t->d_flags, t->d_res);
+  }
+  // ---- PnP on the slots that still track ----------------------------------------------------------------------------------
+  {
+    ProfScope ps(ctx, "pnp");
+    geom_pnp(ctx, B, p->d_cur_lm, p->d_cur_pts, t->d_n_pnp, p->K, p->dist, 100, 8.0f, 0.99, g->d_mask, g->d_model, g->d_result, g->d_inl,
+             g->d_pose, st);
+  }
+  hipLaunchKernelGGL(trk_policy_keyframe_kernel, dim3(nb), dim3(256), 0, st, t->d_state, t->d_count, B, t->d_n_pnp, g->d_result, g->d_pose,
+                     p->d_kf_pose, (long long)c.min_observations_before_triangulation, (long long)c.max_tracking_after_keyframe,
+                     c.max_translation_from_keyframe, c.max_rotation_from_keyframe, t->policy, t->d_n_hf, t->d_flags, t->d_res);
+  // ---- has_parallax on the slots whose key-frame test fired -----------------------------------------------------------
+  { ProfScope ps(ctx, "ransac_h");
+    geom_ransac_h(ctx, B, p->d_cur_kf, p->d_cur_pts, t->d_n_hf, c.ransac_reproj_thresh, 2000, 0.995, g->d_mask2, g->d_model2, g->d_result2, st); }
+  { ProfScope ps(ctx, "ransac_f");
+    geom_ransac_f(ctx, B, p->d_cur_kf, p->d_cur_pts, t->d_n_hf, c.ransac_reproj_thresh, 1000, 0.99, t->d_mask_f, t->d_model_f, t->d_result_f, st); }
+  hipLaunchKernelGGL(trk_policy_parallax_kernel, dim3(1), dim3(1024), 0, st, t->d_n_hf, g->d_result2, t->d_result_f, B, c.f_inlier_thresh,
+                     c.model_score_thresh, t->policy, t->d_flags, t->d_res, t->d_kf_list, t->d_nkf);
+  // ---- add_new_keyframe over the key-frame list --------------------------------------------------------------------------
+  {
+    ProfScope ps(ctx, "kf_gather");
+    const int chunks = 16;
+    hipLaunchKernelGGL(trk_gather_orb0_kernel, dim3(persist_grid((unsigned)B * chunks)), dim3(256), 0, st,
+                       ctx->lk_mem[cur_set] + ctx->lk_level_off[0], ctx->lk_slot_bytes, p->pitch, p->h, o->d_pyr, o->slot_bytes,
+                       t->d_kf_list, t->d_nkf, chunks);
+  }
+  if ((rc = orb_run_device(ctx, p->w, p->h, B, t->d_nkf))) return rc;
+  {
+    ProfScope ps(ctx, "kf_scatter");
+    hipLaunchKernelGGL(trk_orb_capcheck_kernel, dim3(1), dim3(64), 0, st, o->d_slot_base, o->d_kp_base, t->d_nkf, o->cand_cap, o->kp_cap, t->d_err);
+    hipLaunchKernelGGL(trk_scatter_kp_kernel, dim3(16, B), dim3(256), 0, st, o->d_kp, o->d_desc, o->d_kp_base, t->d_kf_list, t->d_nkf, cap,
+                       o->kp_cap, m->d_t, m->d_nt, p->d_kp_xy, t->d_err, t->d_res);
+  }
+  { ProfScope ps(ctx, "match"); match_device(ctx, B, cap, c.lowes_distance_ratio, t->d_kf_list, t->d_nkf); }
+  {
+    ProfScope ps(ctx, "triangulate");
+    geom_triangulate_matches(ctx, B, cap, m->d_out, m->d_nout, p->d_kfkp_xy, p->d_kp_xy, p->d_kf_pose, g->d_pose, g->d_result, p->K, p->d_tri,
+                             p->d_tri_ok, t->d_kf_list, t->d_nkf);
+    hipLaunchKernelGGL(trk_winner_clear_kernel, dim3(4, B), dim3(256), 0, st, t->d_kf_list, t->d_nkf, m->d_nt, cap, p->d_winner);
+    hipLaunchKernelGGL(trk_winner_kernel, dim3(4, B), dim3(256), 0, st, m->d_out, m->d_nout, p->d_tri_ok, cap, t->d_kf_list, t->d_nkf, p->d_winner);
+    hipLaunchKernelGGL(trk_assign_promote_kernel, dim3(B), dim3(1024), 0, st, t->d_kf_list, t->d_nkf, m->d_out, p->d_winner, m->d_nt, p->d_kp_xy,
+                       p->d_kf_has, p->d_kf_lm, p->d_tri, p->d_tri_ok, m->d_nout, cap, p->d_cur_has, p->d_cur_lmk, ctx->d_prev_pts, p->d_lm,
+                       p->d_kf_pts, ctx->d_npts, p->d_kfkp_xy, m->d_q, m->d_t, m->d_nq, p->d_kf_pose, g->d_pose, t->d_count, t->d_res);
+  }
+  // ---- prev_frame_ = new_frame for the others; results -------------------------------------------------------------------
+  hipLaunchKernelGGL(trk_finalize_kernel, dim3(B), dim3(256), 0, st, t->d_state, t->d_count, t->d_flags, p->d_ncur, cap, p->d_cur_pts,
+                     p->d_cur_lm, p->d_cur_kf, ctx->d_prev_pts, p->d_lm, p->d_kf_pts, ctx->d_npts, t->d_res);
+  MVO_HIP(hipMemcpyAsync(t->h_res, t->d_res, (size_t)B * sizeof(mvo_step_result), hipMemcpyDeviceToHost, st));
+  MVO_HIP(hipMemcpyAsync(t->h_err, t->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+  MVO_HIP(hipEventRecord(t->ev_done, st));
+  ctx->lk_cur = cur_set;
+  p->trk_max_n = cap;   // the stage-mask step (mvo_batch_step) sizes its LK grid from this bound
+  p->kf_max_n = cap;
+  t->pending = true;
+  return MVO_OK;
+}
+
+// 1 when the step enqueued last has finished (mvo_batch_track_wait will not block), 0 while it runs.
+extern "C" int mvo_batch_track_poll(mvo_ctx* ctx) {
+  if (!ctx || !ctx->pipe || !ctx->pipe->trk || !ctx->pipe->trk->pending) return 1;
+  return hipEventQuery(ctx->pipe->trk->ev_done) == hipSuccess ? 1 : 0;
+}
+
+extern "C" int mvo_batch_track_wait(mvo_ctx* ctx, mvo_step_result* out) {
+  if (!ctx || !ctx->pipe || !ctx->pipe->trk) return MVO_E_ARG;
+  TrackState* t = ctx->pipe->trk;
+  if (!t->pending) { ctx->set_error("mvo_batch_track_wait: no step in flight"); return MVO_E_ARG; }
+  MVO_HIP(hipEventSynchronize(t->ev_done));
+  t->pending = false;
+  if (out) memcpy(out, t->h_res, (size_t)ctx->B * sizeof(mvo_step_result));
+  if (*t->h_err) {
+    const int e = *t->h_err;
+    ctx->set_error(std::string("mvo_batch_track: device capacity exceeded (") + ((e & TRK_ERR_KEYPOINTS) ? "key-points > max_points " : "") +
+                   ((e & TRK_ERR_CAND) ? "FAST candidates " : "") + ((e & TRK_ERR_KPCAP) ? "dense key-points" : "") + ")");
+    MVO_HIP(hipMemsetAsync(t->d_err, 0, sizeof(int), ctx->stream));
+    return MVO_E_CAPACITY;
+  }
+  return MVO_OK;
+}
+
+extern "C" int mvo_batch_track(mvo_ctx* ctx, int frame_idx, mvo_step_result* out) {
+  int rc = mvo_batch_track_async(ctx, frame_idx);
+  if (rc) return rc;
+  return mvo_batch_track_wait(ctx, out);
+}
+
+// Tracker state of every slot: MVO_TRACK_* (and tracking_count_from_keyframe_).  Blocks until queued work has finished.
+extern "C" int mvo_batch_get_state(mvo_ctx* ctx, int* state, int* tracking_count) {
+  if (!ctx || !ctx->pipe) return MVO_E_ARG;
+  int rc = trk_create(ctx);
+  if (rc) return rc;
+  TrackState* t = ctx->pipe->trk;
+  MVO_HIP(hipStreamSynchronize(ctx->stream));
+  if (state) MVO_HIP(hipMemcpy(state, t->d_state, ctx->B * sizeof(int), hipMemcpyDeviceToHost));
+  if (tracking_count) MVO_HIP(hipMemcpy(tracking_count, t->d_count, ctx->B * sizeof(int), hipMemcpyDeviceToHost));
+  return MVO_OK;
+}
+
+// Called by mvo_batch_seed: every slot starts TRACKING with tracking_count_from_keyframe_ = 0.
+int trk_reset(mvo_ctx* ctx) {
+  if (!ctx->pipe || !ctx->pipe->trk) return MVO_OK;
+  TrackState* t = ctx->pipe->trk;
+  MVO_HIP(hipMemsetAsync(t->d_state, 0, ctx->B * sizeof(int), ctx->stream));
+  MVO_HIP(hipMemsetAsync(t->d_count, 0, ctx->B * sizeof(int), ctx->stream));
+  t->pending = false;
+  return MVO_OK;
+}

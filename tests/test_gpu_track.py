@@ -1,0 +1,165 @@
+"""Frame-batch mode as B x Tracker::update (mvo_batch_track, csrc/track.hip): every slot takes its own branch of the
+reference's per-frame step (src/tracker.cpp:274-333) on the device.  Checked against B independent host mirrors of the
+reference's Tracker (ros2_mono_vo_amd/vo.py) driven by the CPU oracle (tests/track_ref.py): state, what happened on the
+frame (LOST / pose / key-frame test / key-frame), every integer result identical, poses within 1e-6 (contract 1e-4)."""
+import numpy as np
+import pytest
+
+import track_scene as TS
+from pipeline_ref import StreamRef
+from track_ref import TrackRef
+from ros2_mono_vo_amd import Context, _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+INT_KEYS = ("n_prev", "n_tracked", "pnp_ok", "n_pnp_inliers", "score_h", "score_f", "n_keypoints", "n_matches", "n_triangulated",
+            "state", "flags", "tracking_count", "n_tracks")
+
+
+def check(o, e, where):
+    for key in INT_KEYS:
+        assert int(getattr(o, key)) == int(e[key]), (where, key, int(getattr(o, key)), int(e[key]))
+    if e["flags"] & _lib.STEP_POSE:
+        assert np.abs(np.array(o.rvec) - e["rvec"]).max() < 1e-6, where
+        assert np.abs(np.array(o.tvec) - e["tvec"]).max() < 1e-6 * max(1.0, np.abs(e["tvec"]).max()), where
+
+
+def planar_landmarks(K, z=10.0):
+    def f(xy):
+        zz = np.full(len(xy), z, np.float32)
+        return np.stack([(xy[:, 0] - K[0, 2]) / K[0, 0] * zz, (xy[:, 1] - K[1, 2]) / K[1, 1] * zz, zz], 1)
+    return f
+
+
+def test_heterogeneous_streams_take_their_own_branches():
+    """Four rendered true-parallax streams + one featureless one in ONE batch over 25 frames: steady lateral motion (key-frame
+    when tracking_count exceeds 10 and the parallax test passes), a panning camera (H / F every frame from frame 11, never a
+    key-frame: a homography explains a rotation), a fast mover (key-frames by the motion test, some refused by the parallax
+    test), a stream that cuts to other content (few survivors -> key-frame test by count -> 3 landmarks -> LOST)."""
+    N, NF = 26, 1000
+    K = synth.default_K(TS.W, TS.H)
+    data = [TS.stream(kind, N) for kind in TS.KINDS]
+    flat = np.full((N, TS.H, TS.W), 77, np.uint8)
+    B = len(data) + 1
+    with Context(max_width=TS.W, max_height=TS.H, batch=B, nfeatures=NF, max_points=4096, ring_frames=N) as ctx:
+        ctx.batch_set_intrinsics(K)
+        for s in range(B):
+            fr = data[s][0] if s < len(data) else flat
+            for f in range(N):
+                ctx.batch_preload_frame(s, f, fr[f])
+        nk = ctx.batch_seed(0)
+        refs = []
+        for s, (fr, d0) in enumerate(data):
+            r = TrackRef(K, NF)
+            n, xy, lm = r.seed(fr[0], TS.depth_landmarks(K, d0))
+            assert n == nk[s] and np.array_equal(ctx.batch_get_tracks(s), xy)
+            ctx.batch_set_landmarks(s, lm)
+            refs.append(r)
+        assert nk[B - 1] == 0
+        seen = [set() for _ in range(B)]
+        for k in range(1, N):
+            out = ctx.batch_track(k)
+            for s, r in enumerate(refs):
+                e = r.step(data[s][0][k])
+                check(out[s], e, (k, TS.KINDS[s]))
+                seen[s].add((int(out[s].state), int(out[s].flags)))
+            z = out[B - 1]      # featureless stream: nothing to track -> LOST on the first frame, terminal
+            assert z.state == _lib.TRACK_LOST and z.n_tracks == 0 and z.flags == (_lib.STEP_LOST_NOW if k == 1 else 0)
+        P, C, KF = _lib.STEP_POSE, _lib.STEP_KF_CHECKED, _lib.STEP_KEYFRAME
+        assert (0, P) in seen[0] and (0, P | C | KF) in seen[0]                       # lateral: key-frames, nothing refused
+        assert (0, P | C) in seen[1] and not any(f & KF for _, f in seen[1])          # pan: tested every frame, never added
+        assert (0, P | C | KF) in seen[2] and (0, P | C) in seen[2]                   # fast: added and refused
+        assert (1, _lib.STEP_LOST_NOW) in seen[3] and (1, 0) in seen[3]                # cut: lost, then terminal
+        st, cnt = ctx.batch_get_state()
+        assert list(st) == [r.state_code() for r in refs] + [_lib.TRACK_LOST]
+        assert list(cnt[:4]) == [r.tracker.tracking_count_from_keyframe for r in refs]
+
+
+@pytest.mark.parametrize("B,W,H,NF,STEPS", [(4, 1280, 720, 2000, 3), (2, 1920, 1080, 4000, 2)])
+def test_forced_keyframe_policy_at_benchmark_sizes(B, W, H, NF, STEPS):
+    """The worst-case load bench.py can select (policy 1: key-frame branch on every tracked frame) at the sizes it is
+    quoted on - C3 1280x720 / 2000 features with 4 DISTINCT streams, C4 1920x1080 / 4000 - against the oracle flow
+    (tests/pipeline_ref.py), through the device-driven step and through the stage-mask step."""
+    K = synth.default_K(W, H)
+    streams = [synth.gen_stream(W, H, 0x5EED0500 + 7 * s, STEPS + 1) for s in range(B)]
+    refs = []
+    for s in range(B):
+        r = StreamRef(K, NF)
+        r.seed(streams[s][0], planar_landmarks(K))
+        refs.append(r)
+    exp = [[refs[s].step(streams[s][k]) for s in range(B)] for k in range(1, STEPS + 1)]
+    for mode in ("track", "stage_mask"):
+        with Context(max_width=W, max_height=H, batch=B, nfeatures=NF, max_points=8192 if NF > 2000 else 4096, ring_frames=STEPS + 1) as ctx:
+            ctx.batch_set_intrinsics(K)
+            for s in range(B):
+                for f in range(STEPS + 1):
+                    ctx.batch_preload_frame(s, f, streams[s][f])
+            ctx.batch_seed(0)
+            for s in range(B):
+                ctx.batch_set_landmarks(s, planar_landmarks(K)(ctx.batch_get_tracks(s)))
+            if mode == "track":
+                ctx.batch_set_policy(1)
+            for k in range(1, STEPS + 1):
+                out = ctx.batch_track(k) if mode == "track" else ctx.batch_step(k, _lib.STAGE_ALL)
+                for s in range(B):
+                    o, e = out[s], exp[k - 1][s]
+                    for key in ("n_prev", "n_tracked", "n_keypoints", "n_matches", "n_pnp_inliers", "score_h", "score_f", "n_triangulated"):
+                        assert getattr(o, key) == e[key], (mode, k, s, key, getattr(o, key), e[key])
+                    assert bool(o.pnp_ok) == e["pnp_ok"]
+                    assert np.abs(np.array(o.rvec) - e["rvec"]).max() < 1e-6
+                    assert np.abs(np.array(o.tvec) - e["tvec"]).max() < 1e-6 * max(1.0, np.abs(e["tvec"]).max())
+                    if mode == "track":
+                        assert o.flags == _lib.STEP_POSE | _lib.STEP_KF_CHECKED | _lib.STEP_KEYFRAME and o.n_tracks == e["n_new_tracks"]
+
+
+def test_async_ingest_and_interleaved_contexts_match_the_synchronous_run():
+    """Pinned host ring + upload stream + asynchronous steps, two contexts interleaved on the GPU, against one context
+    stepping synchronously over preloaded frames: identical results for every slot and frame."""
+    N, NF = 14, 1000
+    K = synth.default_K(TS.W, TS.H)
+    kinds = ("lateral", "fast", "pan", "cut")
+    data = [TS.stream(kind, N) for kind in kinds]
+
+    def key(o):
+        return (o.n_prev, o.n_tracked, o.pnp_ok, o.n_pnp_inliers, o.score_h, o.score_f, o.n_keypoints, o.n_matches, o.n_triangulated,
+                o.state, o.flags, o.tracking_count, o.n_tracks, tuple(o.rvec), tuple(o.tvec))
+
+    def seed(ctx, slots):
+        ctx.batch_set_intrinsics(K)
+        for i, s in enumerate(slots):
+            ctx.batch_preload_frame(i, 0, data[s][0][0])
+        ctx.batch_seed(0)
+        for i, s in enumerate(slots):
+            ctx.batch_set_landmarks(i, TS.depth_landmarks(K, data[s][1])(ctx.batch_get_tracks(i)))
+
+    with Context(max_width=TS.W, max_height=TS.H, batch=4, nfeatures=NF, max_points=4096, ring_frames=N) as ctx:
+        seed(ctx, range(4))
+        for s in range(4):
+            for f in range(1, N):
+                ctx.batch_preload_frame(s, f, data[s][0][f])
+        want = [[key(o) for o in ctx.batch_track(k)] for k in range(1, N)]
+
+    groups = [(0, 1), (2, 3)]
+    ctxs = [Context(max_width=TS.W, max_height=TS.H, batch=2, nfeatures=NF, max_points=4096, ring_frames=2) for _ in groups]
+    try:
+        pitch = TS.W
+        pins = []
+        for c, g in zip(ctxs, groups):
+            seed(c, g)
+            pins.append(c.host_alloc(2 * 2 * TS.H * pitch).reshape(2, 2, TS.H, pitch))   # [ring][slot][H][W] pinned
+        got = [[None] * 4 for _ in range(N - 1)]
+        for k in range(1, N):
+            e = k % 2
+            for c, g, pin in zip(ctxs, groups, pins):          # enqueue both contexts before collecting either
+                for i, s in enumerate(g):
+                    pin[e, i] = data[s][0][k]
+                c.batch_upload_async(e, pin[e].ctypes.data, TS.W, TS.H, pitch, TS.H * pitch)
+                c.batch_track_async(e)
+            for c, g in zip(ctxs, groups):
+                out = c.batch_track_wait()
+                for i, s in enumerate(g):
+                    got[k - 1][s] = key(out[i])
+        assert got == want
+    finally:
+        for c in ctxs:
+            c.close()
