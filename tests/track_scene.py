@@ -18,7 +18,7 @@ def camera(kind, k):
         c = np.zeros(3)
     elif kind == "fast":
         R = synth.rot_y(-0.1 * k)
-        c = np.array([0.28 * k, 0.02 * k, 0.03 * k])
+        c = np.array([0.16 * k, 0.015 * k, 0.02 * k])
     else:
         R = synth.rot_y(-0.05 * k)
         c = np.array([0.05 * k, 0.0, 0.0])
