@@ -1,21 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py — tracker-step frames/sec of the MI355X-native VO front-end (BASELINE.json metric).
+"""bench.py — tracker-step frames/sec of the MI355X-native VO front-end (BASELINE.json metric, config C3).
 
-One "step" = the reference's steady-state Tracker::update (src/tracker.cpp:274-333) in its worst case
-(key-frame branch every frame) for a batch of B independent 1280x720 mono8 camera streams resident in
-HBM:  pyrDown pyramid + LK (2000-feature tracks) + status/err filter + solvePnPRansac +
-findHomography/findFundamentalMat RANSAC + ORB(2000) detect/describe + knn2/ratio match + triangulation.
-Stages that are not built yet are listed in config["stages_missing"] and make the line a partial one.
+One "step" = the reference's Tracker::update (src/tracker.cpp:274-333) for every camera stream resident on the GPU, each
+stream taking ITS OWN branch on the device (mvo_batch_track, csrc/track.hip): LK + status/err filter -> LOST test ->
+solvePnPRansac -> should_add_keyframe -> [findHomography + findFundamentalMat -> has_parallax -> [ORB + knn2/ratio match +
+triangulate + landmark hand-over]].  Streams are DISTINCT rendered 1280x720 scenes with true parallax (synth_gpu: own
+billboard layout, trajectory and noise per stream), 2000 ORB features, seeded with landmarks from the renderer's depth.
+Per GPU: C contexts x B streams (default 4 x 128), stepped asynchronously so that the one-wavefront-per-stream RANSAC
+chains of one context run beside the wide LK / ORB kernels of another; contexts start 0..10 frames apart so that their
+key-frame steps (every 11th frame under the reference's policy) do not coincide.
 
-Frames are synthetic (ros2_mono_vo_amd.synth) and pre-loaded into the device frame ring
-before the timed region.  value = frames processed by all ranks / max-over-ranks wall time.
+Phases, all on the same tracker state (rank-0 JSON line):
+  value                 reference key-frame policy, frames resident in HBM                       <- the headline
+  value_with_ingest     same, frames in pinned host memory and uploaded asynchronously each step (PCIe inside the metric)
+  always_on_fps         policy 2: LK + PnP only (no key-frame test)
+  keyframe_every_frame_fps   policy 1: key-frame branch on every frame (round 1's headline workload)
+and, against the CPU oracle on the same frames (tests/track_ref.py = the reference's Tracker over oracle/):
+  int_mismatches, rt_max_abs_err (R entries, t relative), cpu_baseline (1 thread) and cpu_baseline_all_cores.
+The line fails (exit 1) if int_mismatches != 0 or rt_max_abs_err > 1e-4.
 
-Multi-GPU (--gpus N under torch.distributed.run): independent streams are sharded across ranks; the only
-collective is one RCCL broadcast of the intrinsics {K, d} from rank 0; scaling "weak".
+Multi-GPU: `--gpus N` without WORLD_SIZE spawns N ranks itself (torch.distributed.run, one process per GPU, RCCL);
+streams are independent, the only collective is one broadcast of the intrinsics; scaling "weak".
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,189 +37,358 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 ALGO_BYTES_PER_LK_POINT = 4261  # 4 levels x (24^2 + 22^2) window bytes + 21 B of point I/O
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+STAGE_TIMERS = ("frame_fanout", "lk_pyramid", "lk_track", "lk_filter", "pnp", "ransac_h", "ransac_f", "kf_gather", "orb_detect", "orb_select",
+                "orb_blur", "orb_describe", "kf_scatter", "match", "triangulate")
+INT_KEYS = ("n_prev", "n_tracked", "pnp_ok", "n_pnp_inliers", "score_h", "score_f", "n_keypoints", "n_matches", "n_triangulated",
+            "state", "flags", "tracking_count", "n_tracks")
 
 
-def make_streams(w, h, n_frames, n_distinct, seed0):
-    from ros2_mono_vo_amd import synth
-    return [synth.gen_stream(w, h, seed0 + 1 + i, n_frames) for i in range(n_distinct)]
-
-
-def planar_landmarks(K, z=10.0):
-    def f(xy):
-        zz = np.full(len(xy), z, np.float32)
-        return np.stack([(xy[:, 0] - K[0, 2]) / K[0, 0] * zz, (xy[:, 1] - K[1, 2]) / K[1, 1] * zz, zz], 1)
-    return f
-
-
-def cpu_baseline(seed, w, h, K, nfeatures, n_frames):
-    """The oracle (CPU restatement, 1 thread) on a bounded sample of the same workload: the first rank's stream 0
-    continued for `n_frames` consecutive full steps (tests/pipeline_ref.py: the same stage list and data flow as
-    mvo_batch_step).  Test infrastructure used as the baseline only — never on the product path."""
-    from pipeline_ref import StreamRef
-    from ros2_mono_vo_amd import synth
-    fr = synth.gen_stream(w, h, seed, n_frames + 1)
-    ref = StreamRef(K, nfeatures)
-    ref.seed(fr[0], planar_landmarks(K))
-    t0 = time.perf_counter()
-    done = 0
-    for k in range(1, min(n_frames + 1, len(fr))):
-        ref.step(fr[k])
-        done += 1
-    dt = time.perf_counter() - t0
-    return done / dt, done
-
-
-STAGE_TIMERS = ("frame_fanout", "lk_pyramid", "lk_track", "lk_filter", "orb_detect", "orb_select", "orb_blur", "orb_describe", "match",
-                "pnp", "ransac_h", "ransac_f", "triangulate")
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=512, help="independent camera streams per GPU (256: 25.3k fps, 512: 26.8k, 1024: 27.5k)")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--contexts", type=int, default=4, help="contexts per GPU, stepped asynchronously")
+    ap.add_argument("--batch", type=int, default=128, help="independent camera streams per context")
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--nfeatures", type=int, default=2000)
-    ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic streams generated per rank")
+    ap.add_argument("--ingest-steps", type=int, default=8, help="steps of the value_with_ingest phase (0 = skip)")
+    ap.add_argument("--extra-steps", type=int, default=5, help="steps of the always-on and key-frame-every-frame phases (0 = skip)")
+    ap.add_argument("--cpu-streams", type=int, default=None, help="streams checked against / timed on the CPU oracle (default: host cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=50, help="consecutive oracle steps timed for cpu_baseline (~0.2 s each)")
-    ap.add_argument("--per-step", action="store_true", help="diagnostic: add the stage timers of every step (step_stage_ms)")
-    ap.add_argument("--stages", type=lambda v: int(v, 0), default=None,
-                    help="diagnostic: MVO_STAGE_* mask to run instead of the full step (the line then lists stages_missing)")
-    args = ap.parse_args()
+    ap.add_argument("--no-stagger", action="store_true", help="start all contexts on the same frame (key-frame steps coincide)")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: rendezvous (gloo) and print the line skeleton")
+    ap.add_argument("--dump-stream", type=int, default=None, help="diagnostic: save the frames + depth of this stream of context 0")
+    ap.add_argument("--dump-path", default="gpurun_out/stream_dump.npz")
+    return ap.parse_args()
 
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks (one per GPU) BEFORE this process touches the GPU,
+    hand the line through and exit with their status.  Never re-execs a process that has initialised HIP."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def _oracle_stream(job):
+    """Worker: the reference's Tracker over the CPU oracle on one stream.  -> (per-step result dicts, seconds, steps)."""
+    K, nfeatures, frames, depth0 = job
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from track_ref import TrackRef
+    from ros2_mono_vo_amd import synth_gpu
+    r = TrackRef(K, nfeatures)
+    r.seed(frames[0], lambda xy: synth_gpu.depth_landmarks(K, depth0, xy))
+    out = []
+    t0 = time.perf_counter()
+    for k in range(1, len(frames)):
+        out.append(r.step(frames[k]))
+    return out, time.perf_counter() - t0, len(frames) - 1
+
+
+def rodrigues(r):
+    r = np.asarray(r, np.float64)
+    th = float(np.sqrt(r @ r))
+    if th < np.finfo(np.float64).eps:
+        return np.eye(3)
+    k = r / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.cos(th) * np.eye(3) + (1 - np.cos(th)) * np.outer(k, k) + np.sin(th) * Kx
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "0"))
+    if world == 0 and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+    world = max(world, 1)
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
     import torch
-    torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dry_run:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from ros2_mono_vo_amd import parallel, synth
 
-    from ros2_mono_vo_amd import Context, _lib, synth
-    from ros2_mono_vo_amd import parallel
+    W, H, B, C, K, Wm = args.width, args.height, args.batch, args.contexts, args.steps, args.warmup
+    K2, K3 = args.ingest_steps, args.extra_steps
+    metric = f"tracker-step frames/sec @{W}x{H}, {args.nfeatures} ORB feats"
+    base_line = {"metric": metric, "value": None, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": None,
+                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/i32 fixed-point + f32/f64", "data": "synthetic"}
+    if args.dry_run:
+        Kmat, _ = parallel.broadcast_intrinsics(synth.default_K(W, H) if rank == 0 else np.zeros((3, 3)), np.zeros(5), dist, device="cpu")
+        assert abs(Kmat[0, 0] - 0.9 * W) < 1e-9
+        dt = parallel.max_over_ranks(0.0, dist, device="cpu")
+        if rank == 0:
+            base_line["config"] = {"workload": "dry run (no GPU work)", "dry_run": True, "ranks": world, "dt": dt}
+            print(json.dumps(base_line), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
-    W, H, B, K, Wm = args.width, args.height, args.batch, args.steps, args.warmup
-    n_frames = K + Wm + 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    from ros2_mono_vo_amd import Context, _lib, synth_gpu
+
     # intrinsics: rank 0 owns them, one RCCL broadcast over xGMI (the path's only collective)
-    Kmat, dcoef = parallel.broadcast_intrinsics(synth.default_K(W, H) if rank == 0 else np.zeros((3, 3)), np.zeros(5), dist,
-                                                device="cuda")
+    Kmat, dcoef = parallel.broadcast_intrinsics(synth.default_K(W, H) if rank == 0 else np.zeros((3, 3)), np.zeros(5), dist, device="cuda")
 
-    streams = make_streams(W, H, n_frames, min(args.distinct, B), 0x5EED0003 + 64 * rank)
-    ctx = Context(max_width=W, max_height=H, batch=B, nfeatures=args.nfeatures, max_points=4096,
-                  ring_frames=n_frames, device=local_rank)
-    ctx.batch_set_intrinsics(Kmat, dcoef)
-    for s in range(B):
-        fr = streams[s % len(streams)]
+    # ---- streams: rendered on this GPU, distinct per stream (and per rank) ------------------------------------------------
+    offs = [0] * C if args.no_stagger else [(11 * c) // C for c in range(C)]           # frames a context starts ahead
+    n_main = Wm + K                                                                     # steps every context takes in phase 1
+    n_frames = 1 + max(offs) + n_main + K2 + 2 * K3 + 1                                  # + 1: the isolated LK launch at the end
+    t_setup = time.perf_counter()
+    bank = synth_gpu.SceneBank(dev)
+    pitch = (W + 63) // 64 * 64
+    frames = torch.zeros((C, n_frames, B, H, pitch), dtype=torch.uint8, device=dev)     # ring layout of a context: [frame][slot][H][pitch]
+    depth0 = np.zeros((C, B, H, W), np.float32)
+    for c in range(C):
+        for s in range(B):
+            prm = bank.stream_params(0x5EED0003 + 100003 * rank + 1009 * c + s)
+            fr, d0 = synth_gpu.render_stream(bank, prm, Kmat, W, H, n_frames)
+            frames[c, :, s, :, :W] = fr
+            depth0[c, s] = d0.cpu().numpy()
+    torch.cuda.synchronize()
+
+    # ---- contexts: frames resident in the device ring, seeded with depth landmarks -------------------------------------
+    ctxs = []
+    for c in range(C):
+        ctx = Context(max_width=W, max_height=H, batch=B, nfeatures=args.nfeatures, max_points=4096, ring_frames=n_frames, device=local_rank)
+        ctx.batch_set_intrinsics(Kmat, dcoef)
         for f in range(n_frames):
-            ctx.batch_preload_frame(s, f, fr[f])
-    ctx.sync()
-    nk = ctx.batch_seed(0)
-    # planar landmarks (Z = 10 m) for the seeded tracks: the similarity-warp stream is a fronto-parallel plane
-    lmf = planar_landmarks(Kmat)
-    for s in range(B):
-        ctx.batch_set_landmarks(s, lmf(ctx.batch_get_tracks(s)))
+            ctx.batch_upload_async(f, frames[c, f].data_ptr(), W, H, pitch, H * pitch)     # device -> device, one copy per frame
+        ctx.sync()
+        ctx.batch_seed(0)
+        for s in range(B):
+            ctx.batch_set_landmarks(s, synth_gpu.depth_landmarks(Kmat, depth0[c, s], ctx.batch_get_tracks(s)))
+        ctxs.append(ctx)
+    # frames of the ingest phase go to pinned host memory; CPU-oracle streams are downloaded; then the device copy is dropped
+    cpu_n = 0
+    if not args.no_cpu_baseline and rank == 0:
+        cpu_n = min(B, args.cpu_streams if args.cpu_streams is not None else (os.cpu_count() or 1))
+    cpu_frames = frames[0, :1 + offs[0] + n_main, :cpu_n, :, :W].permute(1, 0, 2, 3).contiguous().cpu().numpy() if cpu_n else None
+    if args.dump_stream is not None and rank == 0:
+        np.savez_compressed(args.dump_path, frames=frames[0, :1 + n_main, args.dump_stream, :, :W].cpu().numpy(),
+                            depth0=depth0[0, args.dump_stream], K=Kmat)
+    ing0 = [1 + offs[c] + n_main for c in range(C)]                                     # first frame of the ingest phase per context
+    pins = []
+    if K2:
+        for c in range(C):
+            pin = ctxs[c].host_alloc(K2 * B * H * pitch).reshape(K2, B, H, pitch)
+            pin[:] = frames[c, ing0[c]:ing0[c] + K2].cpu().numpy()
+            pins.append(pin)
+    del frames
+    torch.cuda.empty_cache()
+    t_setup = time.perf_counter() - t_setup
 
-    stages = _lib.STAGE_ALL if args.stages is None else args.stages
-    names = {_lib.STAGE_LK: "lk", _lib.STAGE_PNP: "pnp", _lib.STAGE_HF: "ransac_hf", _lib.STAGE_ORB: "orb",
-             _lib.STAGE_MATCH: "match", _lib.STAGE_TRIANG: "triangulate"}
-    stages_missing = [n for b, n in names.items() if not stages & b]
+    def run_phase(n_steps, first_frame, record=None, ingest=False):
+        """Every context takes n_steps steps (its frames first_frame[c] ...), kept in flight independently: as soon as a
+        context's step is collected its next one is enqueued.  -> elapsed seconds (barrier + device sync on both sides)."""
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        if ingest:
+            for c, ctx in enumerate(ctxs):
+                ctx.batch_upload_async(0, pins[c][0].ctypes.data, W, H, pitch, H * pitch)
+        done = [0] * C          # steps collected per context
+        sent = [0] * C          # steps enqueued per context
 
-    for k in range(Wm):
-        ctx.batch_step(1 + k, stages)
-    ctx.profile_reset()
-    ctx.profile_enable(True)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    lk_points = 0
-    last = None
-    step_ms, step_stage, prev_cum, results = [], [], {}, []
-    for k in range(K):
-        ts = time.perf_counter()
-        last = ctx.batch_step(1 + Wm + k, stages)   # synchronous: returns when the step's results are on the host
-        step_ms.append(round((time.perf_counter() - ts) * 1e3, 3))
-        results.append(last)
-        if args.per_step:
-            cum = {n: ctx.profile_read(n)[0] for n in STAGE_TIMERS}
-            step_stage.append({n: round(cum[n] - prev_cum.get(n, 0.0), 3) for n in STAGE_TIMERS})
-            prev_cum = cum
-    ctx.sync()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    ctx.profile_enable(False)
-    lk_points = sum(r.n_prev for res in results for r in res)   # bookkeeping for the roofline, outside the timed region
-    dt = parallel.max_over_ranks(dt, dist, device="cuda")
+        def enqueue(c):
+            k = sent[c]
+            ctxs[c].batch_track_async(k % 2 if ingest else first_frame[c] + k)
+            if ingest and k + 1 < n_steps:      # the next frame's upload overlaps this step (ring of 2 entries)
+                ctxs[c].batch_upload_async((k + 1) % 2, pins[c][k + 1].ctypes.data, W, H, pitch, H * pitch)
+            sent[c] += 1
 
+        for c in range(C):
+            if n_steps:
+                enqueue(c)
+        while min(done) < n_steps:
+            progressed = False
+            for c, ctx in enumerate(ctxs):      # a context whose step has finished is collected and re-armed at once;
+                if done[c] < sent[c] and ctx.batch_track_poll():      # a slow step of one context does not hold the others
+                    out = ctx.batch_track_wait()
+                    if record is not None:
+                        record[c].append(out)
+                    done[c] += 1
+                    if sent[c] < n_steps:
+                        enqueue(c)
+                    progressed = True
+            if not progressed:
+                time.sleep(0.0001)
+        for ctx in ctxs:
+            ctx.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        return parallel.max_over_ranks(time.perf_counter() - t0, dist, device="cuda")
+
+    # ---- phase 0 (untimed): stagger + warm-up.  Context c takes offs[c] extra steps first. -------------------------------
+    rec = [[] for _ in range(C)]
+    for j in range(max(offs)):
+        for c, ctx in enumerate(ctxs):
+            if j < offs[c]:
+                rec[c].append(ctx.batch_track(1 + j))
+    run_phase(Wm, [1 + offs[c] for c in range(C)], rec)
+    for ctx in ctxs:
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+    # ---- phase 1 (the metric): reference policy, frames resident ---------------------------------------------------------
+    n_before = [len(r) for r in rec]
+    dt = run_phase(K, [1 + offs[c] + Wm for c in range(C)], rec)
+    for ctx in ctxs:
+        ctx.profile_enable(False)
     prof = {}
     for name in STAGE_TIMERS:
-        ms, n = ctx.profile_read(name)
+        ms = n = 0
+        for ctx in ctxs:
+            a, b = ctx.profile_read(name)
+            ms += a; n += b
         if n:
             prof[name] = {"ms_total": round(ms, 4), "launches": n, "ms_avg": round(ms / n, 5)}
+    timed = [r for c in range(C) for step in rec[c][n_before[c]:] for r in step]
+    lk_points = sum(r.n_prev for r in timed)
+    flags = np.array([r.flags for r in timed])
+    states_end = np.array([r.state for c in range(C) for r in rec[c][-1]])
+    # ---- phase 2: the same with ingest inside the metric ---------------------------------------------------------------------
+    dt_ing = run_phase(K2, None, None, ingest=True) if K2 else None
+    nxt = [ing0[c] + K2 for c in range(C)]
+    # ---- phase 3 / 4: always-on part only, key-frame branch on every frame --------------------------------------------------
+    dt_on = dt_kf = None
+    if K3:
+        for ctx in ctxs:
+            ctx.batch_set_policy(2)
+        dt_on = run_phase(K3, nxt)
+        for ctx in ctxs:
+            ctx.batch_set_policy(1)
+        dt_kf = run_phase(K3, [n + K3 for n in nxt])
+    # ---- LK kernel alone (contexts one at a time): the roofline's launch duration without other contexts beside it ----------
+    for ctx in ctxs:
+        ctx.batch_set_policy(2)
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+    iso_pts = 0
+    for c, ctx in enumerate(ctxs):
+        iso_pts += sum(r.n_prev for r in ctx.batch_track(nxt[c] + 2 * K3))
+    iso_ms = sum(ctx.profile_read("lk_track")[0] for ctx in ctxs)
+    for ctx in ctxs:
+        ctx.profile_enable(False)
 
     if rank == 0:
-        frames = B * K * world
-        value = frames / dt
-        lk = prof.get("lk_track", {"ms_avg": 0, "launches": 0})
-        algo_bytes = ALGO_BYTES_PER_LK_POINT * (lk_points / max(K, 1))
-        achieved = algo_bytes / (lk["ms_avg"] * 1e-3) / 1e9 if lk["ms_avg"] else 0.0
-        # HBM traffic of the kernel from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes;
-        # profiles/r01_lk_pmc.json holds the measured bytes per tracked point), scaled to this launch's point count.
-        traffic = None
-        valu = {}
+        streams = C * B * world
+        line = dict(base_line)
+        lk = prof.get("lk_track", {"ms_avg": 0.0, "launches": 0})
+        pts_per_launch = lk_points / max(lk["launches"], 1)
+        algo = ALGO_BYTES_PER_LK_POINT * pts_per_launch
+        achieved = algo / (lk["ms_avg"] * 1e-3) / 1e9 if lk["ms_avg"] else 0.0
+        iso_achieved = ALGO_BYTES_PER_LK_POINT * iso_pts / (iso_ms * 1e-3) / 1e9 if iso_ms else 0.0
+        pmc = {}
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_lk_pmc.json")))
-            traffic = int((pmc["fetch_bytes_per_point"] + pmc["write_bytes_per_point"]) * (lk_points / max(K, 1)))
-            valu = pmc.get("sq_pass", {})
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_lk_pmc.json")))
         except Exception:
             pass
-        line = {
-            "metric": "tracker-step frames/sec @1280x720, 2000 ORB feats",
-            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
-            "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8/i32 fixed-point + f32/f64", "data": "synthetic",
-            "config": {"workload": f"C3: {W}x{H} mono8, {args.nfeatures} ORB + LK + PnP-RANSAC + H/F-RANSAC + match + "
-                                   f"triangulate; batch of {B} independent streams per GPU, key-frame branch every frame",
-                       "batch_per_gpu": B, "width": W, "height": H, "nfeatures": args.nfeatures,
-                       "stages": ["lk_pyramid", "lk_track", "lk_filter", "pnp_ransac+refine", "ransac_h", "ransac_f",
-                                  "orb_detect", "orb_describe", "match", "triangulate+landmark_handover"],
-                       "stages_missing": stages_missing, "parallelism": f"streams x{world}",
-                       "mean_tracks_per_frame": round(lk_points / max(B * K, 1), 1),
-                       "mean_keypoints": float(np.mean([r.n_keypoints for r in last])),
-                       "mean_matches": float(np.mean([r.n_matches for r in last])),
-                       "mean_pnp_inliers": float(np.mean([r.n_pnp_inliers for r in last])),
-                       "mean_score_h": float(np.mean([r.score_h for r in last])),
-                       "mean_score_f": float(np.mean([r.score_f for r in last])),
-                       "mean_triangulated": float(np.mean([r.n_triangulated for r in last]))},
-            "roofline": {"bound": "hbm", "kernel": "lk_track_kernel", "achieved": round(achieved, 2),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": lk["ms_avg"],
-                         # the kernel is VALU bound, not memory bound (PMC SQ pass, profiles/r01_lk_pmc.json)
-                         "valu_instructions_per_point": valu.get("valu_instructions_per_point"),
-                         "valu_busy_frac_of_simd_time": valu.get("valu_busy_fraction_of_simd_time_at_2.4GHz")},
+        traffic = int(pmc["hbm_bytes_per_point"] * pts_per_launch) if "hbm_bytes_per_point" in pmc else None
+        line.update({
+            "value": round(streams * K / dt, 2), "ms_per_step": round(dt / K * 1e3, 4),
+            "value_with_ingest": round(streams * K2 / dt_ing, 2) if dt_ing else None,
+            "always_on_fps": round(streams * K3 / dt_on, 2) if dt_on else None,
+            "keyframe_every_frame_fps": round(streams * K3 / dt_kf, 2) if dt_kf else None,
+            "config": {"workload": f"C3: {W}x{H} mono8, {args.nfeatures} ORB; Tracker::update per stream on the device (LK, PnP-RANSAC, key-frame "
+                                   f"policy, H/F-RANSAC, ORB + match + triangulate on key-frames); {C} contexts x {B} distinct rendered "
+                                   f"true-parallax streams per GPU, frames resident in HBM",
+                       "streams_per_gpu": C * B, "contexts_per_gpu": C, "batch_per_context": B, "width": W, "height": H,
+                       "nfeatures": args.nfeatures, "parallelism": f"streams x{world}", "context_start_offsets": offs,
+                       "ingest_steps": K2, "extra_steps": K3,
+                       "mean_tracks_per_frame": round(lk_points / max(len(timed), 1), 1),
+                       "keyframe_test_frac": round(float(np.mean((flags & _lib.STEP_KF_CHECKED) != 0)), 4),
+                       "keyframe_frac": round(float(np.mean((flags & _lib.STEP_KEYFRAME) != 0)), 4),
+                       "streams_tracking_at_end": int((states_end == _lib.TRACK_TRACKING).sum()), "streams": C * B,
+                       "setup_s": round(t_setup, 1)},
+            "roofline": {"bound": "hbm", "kernel": "lk_track_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "traffic_source": pmc.get("source", "none: run the rocprofv3 PMC passes of profiles/README"),
+                         "algorithmic_bytes_per_launch": int(algo), "points_per_launch": round(pts_per_launch, 1),
+                         "avg_launch_ms": lk["ms_avg"], "launches": lk["launches"],
+                         "note": "launches of the timed region run beside other contexts' kernels; `isolated` = the same kernel with the GPU to itself",
+                         "isolated": {"achieved": round(iso_achieved, 2), "frac": round(iso_achieved / HBM_PEAK_GBS, 5),
+                                      "ms_per_launch": round(iso_ms / C, 4), "points_per_launch": round(iso_pts / C, 1)},
+                         "valu_instructions_per_point": pmc.get("valu_instructions_per_point"),
+                         "valu_issue_frac": pmc.get("valu_issue_frac")},
             "stage_ms": prof,
-            "step_ms": step_ms,
-        }
-        if step_stage:
-            line["step_stage_ms"] = step_stage
-        if not args.no_cpu_baseline:
-            fps, nfr = cpu_baseline(0x5EED0003 + 1, W, H, Kmat, args.nfeatures, args.cpu_frames)
-            line["cpu_baseline"] = {"value": round(fps, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-                                    "sample": f"oracle (CPU restatement of OpenCV-4.6 semantics, not OpenCV), stream 0, "
-                                              f"{nfr} consecutive full steps (same stage list and data flow), 1 thread"}
+        })
+        rcode = 0
+        if cpu_n:
+            # the oracle on the same frames: parity of the timed run + the CPU baseline, 1 thread and all cores
+            jobs = [(Kmat, args.nfeatures, cpu_frames[s], depth0[0, s]) for s in range(cpu_n)]
+            one, t1, n1 = _oracle_stream(jobs[0])
+            allr, t_all = [one], None
+            cores = os.cpu_count() or 1
+            if cpu_n > 1:
+                import multiprocessing as mp
+                t0 = time.perf_counter()
+                with mp.get_context("fork").Pool(min(cores, cpu_n - 1)) as pool:
+                    rest = pool.map(_oracle_stream, jobs[1:])
+                t_all = time.perf_counter() - t0
+                allr += [r[0] for r in rest]
+            mism, rt_err, checked, worst, ill = 0, 0.0, 0, None, 0
+            for s in range(cpu_n):
+                for k, e in enumerate(allr[s]):
+                    o = rec[0][k][s]
+                    checked += 1
+                    mism += sum(int(getattr(o, key)) != int(e[key]) for key in INT_KEYS)
+                    if (e["flags"] & _lib.STEP_POSE) and (np.linalg.norm(e["rvec"]) > np.pi or np.linalg.norm(e["tvec"]) > 1e3):
+                        ill += 1      # the ORACLE's own pose is not a pose (LM diverged from an ill-conditioned DLT start): counted, not compared
+                    elif e["flags"] & _lib.STEP_POSE:
+                        err = max(float(np.abs(rodrigues(o.rvec) - rodrigues(e["rvec"])).max()),
+                                  float(np.abs(np.array(o.tvec) - e["tvec"]).max() / max(1.0, float(np.linalg.norm(e["tvec"])))))
+                        if err > rt_err:
+                            rt_err = err
+                            worst = {"stream": s, "frame": k + 1, "err": err, "rvec": list(o.rvec), "tvec": list(o.tvec),
+                                     "rvec_cpu": [float(v) for v in e["rvec"]], "tvec_cpu": [float(v) for v in e["tvec"]],
+                                     "n_tracked": int(o.n_tracked), "n_pnp_inliers": int(o.n_pnp_inliers)}
+            model = "unknown"
+            try:
+                model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+            except Exception:
+                pass
+            line["int_mismatches"] = mism
+            line["rt_max_abs_err"] = rt_err
+            line["rt_worst"] = worst
+            line["rt_frames_oracle_pose_diverged"] = ill
+            line["parity_checked"] = f"{cpu_n} streams x {len(allr[0])} frames of context 0 (warm-up + timed steps) vs the CPU oracle: {checked} frame results"
+            line["cpu_baseline"] = {"value": round(n1 / t1, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+                                    "sample": f"oracle (CPU restatement of OpenCV-4.6 semantics, not OpenCV) behind the reference's Tracker "
+                                              f"(tests/track_ref.py), stream 0 of context 0, {n1} consecutive frames of the benchmarked run, 1 thread"}
+            if t_all:
+                nw = min(cores, cpu_n - 1)
+                line["cpu_baseline_all_cores"] = {"value": round(sum(r[2] for r in rest) / t_all, 3), "unit": "frames/s", "cores": nw,
+                                                  "host_cores": cores, "cpu_model": model, "kind": "port",
+                                                  "sample": f"{cpu_n - 1} streams x {n1} frames, one process per stream on {nw} cores"}
+            if mism != 0 or rt_err > 1e-4:
+                rcode = 1
         print(json.dumps(line), flush=True)
-    ctx.close()
+    else:
+        rcode = 0
+    for ctx in ctxs:
+        ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+    sys.exit(rcode)
 
 
 if __name__ == "__main__":

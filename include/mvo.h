@@ -82,6 +82,7 @@ typedef struct mvo_config {
 } mvo_config;
 
 void mvo_config_default(mvo_config* cfg);
+/* On failure *out is NULL and nothing stays allocated. */
 int mvo_create(const mvo_config* cfg, mvo_ctx** out);
 void mvo_destroy(mvo_ctx* ctx);
 const char* mvo_last_error(const mvo_ctx* ctx);
@@ -227,8 +228,9 @@ int mvo_batch_step(mvo_ctx* ctx, int frame_idx, unsigned stages, mvo_step_result
  *   mvo_batch_track_wait   block until it has finished, copy the per-slot results to out[batch] (may be NULL);
  *                          MVO_E_CAPACITY if a device-side capacity was exceeded (results clamped)
  *   mvo_batch_track        both
- *   mvo_batch_set_policy   0: the reference's key-frame policy (default); 1: key-frame branch on every tracked frame
- *                          (worst-case load for benchmarking; LOST / ABORTED handling unchanged)
+ *   mvo_batch_set_policy   0: the reference's key-frame policy (default); benchmarking loads (LOST / ABORTED handling
+ *                          unchanged): 1 = key-frame branch on every tracked frame (worst case), 2 = never a key-frame
+ *                          (the always-on part of the step: LK + PnP)
  *   mvo_batch_get_state    MVO_TRACK_* and tracking_count_from_keyframe_ of every slot (blocks) */
 int mvo_batch_track_async(mvo_ctx* ctx, int frame_idx);
 int mvo_batch_track_poll(mvo_ctx* ctx);

@@ -54,16 +54,22 @@ struct RansacArgs {
 #endif
 #define RS_NW (RS_T / 64)
 
-template <class M>
-__global__ __launch_bounds__(RS_T, RS_WAVES_PER_EU) void ransac_kernel(RansacArgs A) {
+// NW wavefronts per problem: every wave solves M::CH hypotheses of a round in its own LDS workspaces, so a round is NW
+// times as wide at the same latency.  The easy case (consensus after a handful of iterations) costs the same as with one
+// wave; a hard stream - findHomography under true parallax needs hundreds to 2000 iterations - finishes NW times sooner,
+// and the batch launch lasts as long as its hardest stream.  Candidate c of a round belongs to wave c / CPW, lane c % CPW.
+template <class M, int NW>
+__global__ __launch_bounds__(64 * NW, RS_WAVES_PER_EU) void ransac_kernel(RansacArgs A) {
+  constexpr int RS_TT = 64 * NW;
+  static_assert(NW == 1 || !M::WIDE, "wide (private-memory) rounds are a single-wave mode");
   // Round width.  The first round (and any round with few iterations left) solves CH0 = M::CH hypotheses, whose dense
   // matrices live in LDS; when more than that many iterations are still owed, the round is 64 wide and lanes >= CH0 keep
   // their matrices in private memory (slower per solve, four times the hypotheses per round) - the tail of a hard
   // problem otherwise gates the whole batch launch.
-  constexpr int CH0 = M::CH, RS_CH = M::WIDE ? 64 : M::CH;
+  constexpr int CH0 = M::CH, RS_CH = (M::WIDE ? 64 : M::CH) * NW;
   // per-lane workspace stride: == 1 (mod 32) doubles, so lane-uniform 8-byte accesses of 16 lanes fall into distinct banks
   constexpr int WSS = M::WS > 0 ? ((M::WS + 30) / 32) * 32 + 1 : 1;
-  __shared__ double s_ws[(M::WS > 0 ? CH0 : 1) * WSS];
+  __shared__ double s_ws[(M::WS > 0 ? CH0 * NW : 1) * WSS];
   __shared__ int s_att[RS_CH][M::MP];
   __shared__ int s_idx[RS_CH][M::MP];
   __shared__ double s_models[RS_CH][M::MAXM][M::MS];
@@ -71,8 +77,8 @@ __global__ __launch_bounds__(RS_T, RS_WAVES_PER_EU) void ransac_kernel(RansacArg
   __shared__ int s_cnt[RS_CH][M::MAXM];
   __shared__ double s_best[M::MS];
   __shared__ int s_ctl[8];  // 0: npass, 1: done, 2: maxGood, 3: iter, 4: niters, 5: consec_fail, 6: ok, 7: models scored
-  __shared__ int s_wpass[RS_NW];
-  __shared__ unsigned long long s_wmask[RS_NW];
+  __shared__ int s_wpass[NW];
+  __shared__ unsigned long long s_wmask[NW];
   __shared__ unsigned long long s_rng;
   __shared__ double s_minmed;
 
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(RS_T, RS_WAVES_PER_EU) void ransac_kernel(RansacArg
   const float t = (float)(A.thr * A.thr);
 
   if (count < M::MP) {
-    for (int i = tid; i < count; i += RS_T) mask[i] = 0;
+    for (int i = tid; i < count; i += RS_TT) mask[i] = 0;
     if (tid == 0) { result[0] = 0; result[1] = 0; result[2] = 0; result[3] = 0; result[4] = 0; }
     return;
   }
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(RS_T, RS_WAVES_PER_EU) void ransac_kernel(RansacArg
     }
     __syncthreads();
     int ok = s_ctl[6];
-    for (int i = tid; i < count; i += RS_T) mask[i] = ok ? 1 : 0;
+    for (int i = tid; i < count; i += RS_TT) mask[i] = ok ? 1 : 0;
     if (tid == 0) { result[0] = ok; result[1] = ok ? count : 0; result[2] = 1; result[3] = 1; result[4] = 1; }
     return;
   }
@@ -131,7 +137,9 @@ __global__ __launch_bounds__(RS_T, RS_WAVES_PER_EU) void ransac_kernel(RansacArg
 #define RS_TICK(k)
 #endif
   for (;;) {
-    const int ch = (M::WS > 0 && s_ctl[4] - s_ctl[3] <= CH0) || (M::WS > 0 && s_ctl[3] == 0) ? CH0 : RS_CH;  // uniform
+    const int ch = NW > 1 ? RS_CH : ((M::WS > 0 && s_ctl[4] - s_ctl[3] <= CH0) || (M::WS > 0 && s_ctl[3] == 0) ? CH0 : RS_CH);  // uniform
+    const int cpw = ch / NW;                                  // candidates per wave
+    const int cand = lane < cpw ? wave * cpw + lane : -1;     // this thread's candidate / hypothesis of the round
     // ---- 1. candidate samples, OpenCV's getSubset draw order (sequential RNG stream, lane 0) ----------
     if (tid == 0) {
       GlRng rng(s_rng);
@@ -155,9 +163,9 @@ __global__ __launch_bounds__(RS_T, RS_WAVES_PER_EU) void ransac_kernel(RansacArg
     // ---- 2. checkSubset in parallel (one candidate per lane) + ordered compaction over the 4 waves -------
     float ms1[M::MP * M::PT1], ms2[M::MP * M::PT2];
     bool pass = false;
-    if (tid < ch) {
+    if (cand >= 0) {
       for (int i = 0; i < M::MP; i++) {
-        int id = s_att[tid][i];
+        int id = s_att[cand][i];
         for (int k = 0; k < M::PT1; k++) ms1[i * M::PT1 + k] = m1[(size_t)id * M::PT1 + k];
         for (int k = 0; k < M::PT2; k++) ms2[i * M::PT2 + k] = m2[(size_t)id * M::PT2 + k];
       }
@@ -169,13 +177,13 @@ __global__ __launch_bounds__(RS_T, RS_WAVES_PER_EU) void ransac_kernel(RansacArg
     int pos = __popcll(bm & ((1ull << lane) - 1));
     for (int w = 0; w < wave; w++) pos += s_wpass[w];
     if (pass)
-      for (int i = 0; i < M::MP; i++) s_idx[pos][i] = s_att[tid][i];
+      for (int i = 0; i < M::MP; i++) s_idx[pos][i] = s_att[cand][i];
     if (tid == 0) {
       // OpenCV gives up on an iteration after 10000 consecutive failing attempts: walk the pass bits in order
       int np = 0, run = s_ctl[5];
       bool abort_ = false;
-      const int CPW = ch;  // candidates held by the wave's ballot
-      for (int w = 0; w < RS_NW; w++) {
+      const int CPW = cpw;  // candidates held by a wave's ballot
+      for (int w = 0; w < NW; w++) {
         unsigned long long m = s_wmask[w];
         np += __popcll(m);
         if (m == 0) { run += CPW; abort_ |= run >= 10000; }
@@ -200,26 +208,26 @@ __global__ __launch_bounds__(RS_T, RS_WAVES_PER_EU) void ransac_kernel(RansacArg
     // ---- 3. minimal solver, one hypothesis per lane; only as many as can still be consumed ---------------
     const int nsolve = min(npass, s_ctl[4] - s_ctl[3]);
     int nm = 0;
-    if (tid < nsolve) {
+    if (cand >= 0 && cand < nsolve) {
       for (int i = 0; i < M::MP; i++) {
-        int id = s_idx[tid][i];
+        int id = s_idx[cand][i];
         for (int k = 0; k < M::PT1; k++) ms1[i * M::PT1 + k] = m1[(size_t)id * M::PT1 + k];
         for (int k = 0; k < M::PT2; k++) ms2[i * M::PT2 + k] = m2[(size_t)id * M::PT2 + k];
       }
       double models[M::MAXM * M::MS];
       double priv[M::WS > 0 && M::WIDE ? M::WS : 1];  // lanes >= CH0 of a wide round
-      nm = M::solve(A.P, ms1, ms2, models, M::WS > 0 ? (!M::WIDE || tid < CH0 ? s_ws + tid * WSS : priv) : s_ws);
+      nm = M::solve(A.P, ms1, ms2, models, M::WS > 0 ? (!M::WIDE || cand < CH0 ? s_ws + cand * WSS : priv) : s_ws);
       if (nm < 0) nm = 0;
       if (nm > M::MAXM) nm = M::MAXM;
-      s_nmodels[tid] = nm;
+      s_nmodels[cand] = nm;
       for (int q = 0; q < nm; q++)
-        for (int k = 0; k < M::MS; k++) s_models[tid][q][k] = models[q * M::MS + k];
+        for (int k = 0; k < M::MS; k++) s_models[cand][q][k] = models[q * M::MS + k];
     }
     __syncthreads();
     RS_TICK(2)
     // ---- 4. scoring: hypothesis = tid % RS_CH, point partition = tid / RS_CH; integer inlier counts ------------
     {
-      const int parts = RS_T / ch, hyp = tid % ch, part = tid / ch;
+      const int parts = RS_TT / ch, hyp = tid % ch, part = tid / ch;
       if (lmeds) {
         if (part == 0 && hyp < nsolve) {
           const int nmh = s_nmodels[hyp];
@@ -291,7 +299,7 @@ __global__ __launch_bounds__(RS_T, RS_WAVES_PER_EU) void ransac_kernel(RansacArg
       sc.init(A.P, s_best);
       int good = 0;
 #pragma unroll 1
-      for (int i = tid; i < count; i += RS_T) {
+      for (int i = tid; i < count; i += RS_TT) {
         int f = sc.err(m1 + (size_t)i * M::PT1, m2 + (size_t)i * M::PT2) <= ts ? 1 : 0;
         mask[i] = (u8)f;
         good += f;
@@ -300,10 +308,10 @@ __global__ __launch_bounds__(RS_T, RS_WAVES_PER_EU) void ransac_kernel(RansacArg
       if (tid < M::MS) out_model[tid] = s_best[tid];
       __syncthreads();
       good = s_ctl[2];
-      if (good < M::MP) for (int i = tid; i < count; i += RS_T) mask[i] = 0;   // findFundamentalMat returns an empty Mat
+      if (good < M::MP) for (int i = tid; i < count; i += RS_TT) mask[i] = 0;   // findFundamentalMat returns an empty Mat
       if (tid == 0) { result[0] = good >= M::MP; result[1] = good; result[2] = s_ctl[3]; result[3] = s_ctl[4]; result[4] = s_ctl[7]; }
     } else {
-      for (int i = tid; i < count; i += RS_T) mask[i] = 0;
+      for (int i = tid; i < count; i += RS_TT) mask[i] = 0;
       if (tid == 0) { result[0] = 0; result[1] = 0; result[2] = s_ctl[3]; result[3] = s_ctl[4]; result[4] = s_ctl[7]; }
     }
     return;
@@ -313,10 +321,10 @@ __global__ __launch_bounds__(RS_T, RS_WAVES_PER_EU) void ransac_kernel(RansacArg
     typename M::Scorer sc;
     sc.init(A.P, s_best);
 #pragma unroll 1
-    for (int i = tid; i < count; i += RS_T) mask[i] = sc.err(m1 + (size_t)i * M::PT1, m2 + (size_t)i * M::PT2) <= t ? 1 : 0;
+    for (int i = tid; i < count; i += RS_TT) mask[i] = sc.err(m1 + (size_t)i * M::PT1, m2 + (size_t)i * M::PT2) <= t ? 1 : 0;
     if (tid < M::MS) out_model[tid] = s_best[tid];
   } else {
-    for (int i = tid; i < count; i += RS_T) mask[i] = 0;
+    for (int i = tid; i < count; i += RS_TT) mask[i] = 0;
   }
   if (tid == 0) { result[0] = maxGood > 0; result[1] = maxGood; result[2] = s_ctl[3]; result[3] = s_ctl[4]; result[4] = s_ctl[7]; }
 #ifdef RS_TIMING
@@ -839,7 +847,7 @@ void geom_state_destroy(mvo_ctx* ctx) {
   ctx->geom = nullptr;
 }
 
-template <class M>
+template <class M, int NW = 1>
 static void launch_ransac(mvo_ctx* ctx, hipStream_t st, int nslots, const float* m1, const float* m2, int stride1, int stride2,
                           const int* d_n, double thr, double conf, int max_iters, const ModelParams& P, u8* mask, int mask_stride,
                           double* model, int* result) {
@@ -847,7 +855,7 @@ static void launch_ransac(mvo_ctx* ctx, hipStream_t st, int nslots, const float*
   A.m1 = m1; A.m2 = m2; A.stride1 = stride1; A.stride2 = stride2; A.n = d_n;
   A.thr = thr; A.conf = conf; A.max_iters = max_iters; A.cap = ctx->maxpts; A.P = P;
   A.mask = mask; A.mask_stride = mask_stride; A.model = model; A.result = result;
-  hipLaunchKernelGGL(ransac_kernel<M>, dim3(nslots), dim3(RS_T), 0, st, A);
+  hipLaunchKernelGGL((ransac_kernel<M, NW>), dim3(nslots), dim3(64 * NW), 0, st, A);
 }
 
 // Device-level drivers used by the pipeline (inputs already resident, all slots per launch).
@@ -855,7 +863,7 @@ int geom_ransac_h(mvo_ctx* ctx, int nslots, const float* p1, const float* p2, co
                   u8* mask, double* model, int* result, hipStream_t st) {
   if (!st) st = ctx->stream;
   ModelParams P{};
-  launch_ransac<HModel>(ctx, st, nslots, p1, p2, ctx->maxpts * 2, ctx->maxpts * 2, d_n, thr, conf, max_iters, P, mask, ctx->maxpts, model, result);
+  launch_ransac<HModel, 4>(ctx, st, nslots, p1, p2, ctx->maxpts * 2, ctx->maxpts * 2, d_n, thr, conf, max_iters, P, mask, ctx->maxpts, model, result);
   return MVO_OK;
 }
 int geom_ransac_f(mvo_ctx* ctx, int nslots, const float* p1, const float* p2, const int* d_n, double thr, int max_iters, double conf,

@@ -72,12 +72,12 @@ __global__ void color2gray_kernel(const u8* __restrict__ src, int spitch, u8* __
 int upload_gray(mvo_ctx* ctx, const uint8_t* img, int w, int h, int stride, int channels, u8* d_dst,
                 int dpitch, int slot) {
   if (channels == 1) {
-    MVO_HIP(hipMemcpy2DAsync(d_dst, dpitch, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
+    MVO_HIP(hipMemcpy2DAsync(d_dst, dpitch, img, stride, w, h, hipMemcpyDefault, ctx->stream));
   } else if (channels == 3 || channels == -3 || channels == 4 || channels == -4) {
     const int bpp = channels < 0 ? -channels : channels;
     u8* st = ctx->d_stage + (size_t)slot * ctx->stage_slot_bytes;
     int spitch = align_up(w * bpp, 64);
-    MVO_HIP(hipMemcpy2DAsync(st, spitch, img, stride, (size_t)w * bpp, h, hipMemcpyHostToDevice, ctx->stream));
+    MVO_HIP(hipMemcpy2DAsync(st, spitch, img, stride, (size_t)w * bpp, h, hipMemcpyDefault, ctx->stream));
     dim3 grid((w + 255) / 256, h);
     hipLaunchKernelGGL(color2gray_kernel, grid, dim3(256), 0, ctx->stream, st, spitch, d_dst, dpitch, w, h, bpp, channels < 0 ? 1 : 0);
   } else {
@@ -87,7 +87,7 @@ int upload_gray(mvo_ctx* ctx, const uint8_t* img, int w, int h, int stride, int 
   return MVO_OK;
 }
 
-extern "C" int mvo_create(const mvo_config* cfg, mvo_ctx** out) {
+static int mvo_create_impl(const mvo_config* cfg, mvo_ctx** out) {
   if (!cfg || !out) return MVO_E_ARG;
   if (cfg->max_width < 32 || cfg->max_height < 32 || cfg->batch < 1 || cfg->max_points < 16) return MVO_E_ARG;
   int ndev = 0;
@@ -135,6 +135,21 @@ extern "C" int mvo_create(const mvo_config* cfg, mvo_ctx** out) {
   return MVO_OK;
 }
 
+// On failure nothing is left behind: the half-built context is destroyed and *out is NULL (the error text of a failed
+// create is not retrievable through mvo_last_error; the status code says which class of failure it was).
+extern "C" int mvo_create(const mvo_config* cfg, mvo_ctx** out) {
+  if (!out) return MVO_E_ARG;
+  *out = nullptr;
+  mvo_ctx* ctx = nullptr;
+  const int rc = mvo_create_impl(cfg, &ctx);
+  if (rc != MVO_OK) {
+    if (ctx) mvo_destroy(ctx);
+    return rc;
+  }
+  *out = ctx;
+  return MVO_OK;
+}
+
 extern "C" void mvo_destroy(mvo_ctx* ctx) {
   if (!ctx) return;
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
@@ -159,7 +174,7 @@ extern "C" const char* mvo_last_error(const mvo_ctx* ctx) { return ctx ? ctx->er
 extern "C" int mvo_sync(mvo_ctx* ctx) {
   if (!ctx) return MVO_E_ARG;
   MVO_HIP(hipStreamSynchronize(ctx->stream));
-  return MVO_OK;
+  return trk_sync_upload(ctx);   // and the upload stream of the frame-batch ring
 }
 
 extern "C" void* mvo_stream(mvo_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }

@@ -234,6 +234,8 @@ int pipe_state_create(mvo_ctx* ctx);
 void pipe_state_destroy(mvo_ctx* ctx);
 void trk_destroy(mvo_ctx* ctx);   // track.hip
 int trk_reset(mvo_ctx* ctx);
+int trk_wait_upload(mvo_ctx* ctx, int frame_idx);   // ctx->stream waits for an asynchronous upload into ring entry frame_idx
+int trk_sync_upload(mvo_ctx* ctx);                  // host waits for the upload stream
 void lk_filter_compact_launch(mvo_ctx* ctx, hipStream_t st);   // pipeline.hip: status/err filter of all slots
 
 // device-level stage drivers (all slots per launch)

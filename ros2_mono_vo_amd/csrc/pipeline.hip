@@ -412,6 +412,7 @@ extern "C" int mvo_batch_seed(mvo_ctx* ctx, int frame_idx, int* n_keypoints) {
   int rc;
   LkLevels L = lk_levels(p->w, p->h, ctx->cfg.lk_win, ctx->cfg.lk_max_level);
   ctx->lk_cur = 0;
+  if ((rc = trk_wait_upload(ctx, frame_idx))) return rc;
   if ((rc = pipe_load_frame(ctx, frame_idx, ctx->lk_cur))) return rc;
   lk_build_pyramid(ctx, ctx->lk_cur, L, ctx->B);
   std::vector<int> base;
@@ -473,6 +474,7 @@ extern "C" int mvo_batch_step(mvo_ctx* ctx, int frame_idx, unsigned stages, mvo_
   //   s_lk   (waits for the fan-out) pyrDown pyramid -> LK -> status/err filter            -- beside ORB detect
   //   s_pnp  (waits for LK) PnP RANSAC + refine        s_hf  (waits for LK) H RANSAC, F RANSAC
   // so the host-side key-point selection overlaps LK and the RANSAC chains instead of idling the device.
+  if ((rc = trk_wait_upload(ctx, frame_idx))) return rc;
   if ((rc = pipe_load_frame(ctx, frame_idx, cur_set))) return rc;
   MVO_HIP(hipEventRecord(p->ev_frame, ctx->stream));
   const bool do_orb = stages & MVO_STAGE_ORB;

@@ -40,7 +40,8 @@ struct TrackState {
   mvo_step_result* d_res = nullptr;  // [B]
   mvo_step_result* h_res = nullptr;  // pinned
   int* h_err = nullptr;              // pinned [1]
-  int policy = 0;              // 0: the reference's key-frame policy, 1: key-frame branch on every tracked frame (worst case)
+  int policy = 0;              // 0: the reference's key-frame policy, 1: key-frame branch on every tracked frame (worst case),
+                               // 2: never a key-frame (the always-on part of the step: LK + PnP)
   bool pending = false;
   hipEvent_t ev_done = nullptr;
 };
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(256) void trk_policy_keyframe_kernel(int* __restric
         }
       }
       if (policy == 1) add = true;
+      if (policy == 2) add = false;
       if (add) { nhf = n; flags[s] |= MVO_STEP_KF_CHECKED; }
     }
   }
@@ -504,7 +506,7 @@ extern "C" int mvo_host_alloc(size_t bytes, void** out) {
 extern "C" int mvo_host_free(void* p) { return (!p || hipHostFree(p) == hipSuccess) ? MVO_OK : MVO_E_HIP; }
 
 extern "C" int mvo_batch_set_policy(mvo_ctx* ctx, int policy) {
-  if (!ctx || !ctx->pipe || ctx->pipe->ring <= 0 || (policy != 0 && policy != 1)) return MVO_E_ARG;
+  if (!ctx || !ctx->pipe || ctx->pipe->ring <= 0 || policy < 0 || policy > 2) return MVO_E_ARG;
   int rc = trk_create(ctx);
   if (rc) return rc;
   ctx->pipe->trk->policy = policy;
@@ -526,21 +528,21 @@ extern "C" int mvo_batch_upload_async(mvo_ctx* ctx, int frame_idx, const uint8_t
   if (p->rd_pending[frame_idx]) { MVO_HIP(hipStreamWaitEvent(p->s_up, p->ev_rd[frame_idx], 0)); p->rd_pending[frame_idx] = 0; }
   u8* dst = p->d_ring + (size_t)frame_idx * ctx->B * p->frame_bytes;
   if (stride == p->pitch && slot_stride == p->frame_bytes) {
-    MVO_HIP(hipMemcpyAsync(dst, frames, p->frame_bytes * ctx->B, hipMemcpyHostToDevice, p->s_up));
+    MVO_HIP(hipMemcpyAsync(dst, frames, p->frame_bytes * ctx->B, hipMemcpyDefault, p->s_up));
   } else if (slot_stride == (size_t)stride * h) {
     // one 2-D copy: the B images are one tall image of B*h rows on the host; on the device the slots are frame_bytes
     // = pitch * maxh apart, which equals pitch * h only when h == maxh
     if ((size_t)p->pitch * h == p->frame_bytes) {
-      MVO_HIP(hipMemcpy2DAsync(dst, p->pitch, frames, stride, w, (size_t)h * ctx->B, hipMemcpyHostToDevice, p->s_up));
+      MVO_HIP(hipMemcpy2DAsync(dst, p->pitch, frames, stride, w, (size_t)h * ctx->B, hipMemcpyDefault, p->s_up));
     } else {
       for (int s = 0; s < ctx->B; s++)
         MVO_HIP(hipMemcpy2DAsync(dst + (size_t)s * p->frame_bytes, p->pitch, frames + (size_t)s * slot_stride, stride, w, h,
-                                 hipMemcpyHostToDevice, p->s_up));
+                                 hipMemcpyDefault, p->s_up));
     }
   } else {
     for (int s = 0; s < ctx->B; s++)
       MVO_HIP(hipMemcpy2DAsync(dst + (size_t)s * p->frame_bytes, p->pitch, frames + (size_t)s * slot_stride, stride, w, h,
-                               hipMemcpyHostToDevice, p->s_up));
+                               hipMemcpyDefault, p->s_up));
   }
   MVO_HIP(hipEventRecord(p->ev_up[frame_idx], p->s_up));
   p->up_pending[frame_idx] = 1;
@@ -567,7 +569,7 @@ extern "C" int mvo_batch_track_async(mvo_ctx* ctx, int frame_idx) {
   const int prev_set = ctx->lk_cur, cur_set = ctx->lk_cur ^ 1;
   const int nb = (B + 255) / 256;
 
-  if (p->up_pending[frame_idx]) { MVO_HIP(hipStreamWaitEvent(st, p->ev_up[frame_idx], 0)); p->up_pending[frame_idx] = 0; }
+  if ((rc = trk_wait_upload(ctx, frame_idx))) return rc;
   // ---- LK: frame -> "cur" pyramid; dense work list over the slots that are tracking ----------------------------------
   {
     ProfScope ps(ctx, "frame_fanout");
@@ -684,6 +686,20 @@ extern "C" int mvo_batch_get_state(mvo_ctx* ctx, int* state, int* tracking_count
   MVO_HIP(hipStreamSynchronize(ctx->stream));
   if (state) MVO_HIP(hipMemcpy(state, t->d_state, ctx->B * sizeof(int), hipMemcpyDeviceToHost));
   if (tracking_count) MVO_HIP(hipMemcpy(tracking_count, t->d_count, ctx->B * sizeof(int), hipMemcpyDeviceToHost));
+  return MVO_OK;
+}
+
+// A step / seed on ctx->stream that reads ring entry `frame_idx` waits for an upload still in flight into it.
+int trk_wait_upload(mvo_ctx* ctx, int frame_idx) {
+  PipeState* p = ctx->pipe;
+  if (!p || p->up_pending.empty() || frame_idx < 0 || frame_idx >= (int)p->up_pending.size()) return MVO_OK;
+  if (p->up_pending[frame_idx]) { MVO_HIP(hipStreamWaitEvent(ctx->stream, p->ev_up[frame_idx], 0)); p->up_pending[frame_idx] = 0; }
+  return MVO_OK;
+}
+
+int trk_sync_upload(mvo_ctx* ctx) {
+  PipeState* p = ctx->pipe;
+  if (p && p->s_up) MVO_HIP(hipStreamSynchronize(p->s_up));
   return MVO_OK;
 }
 
