@@ -532,7 +532,9 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
         int q = 0;
         for (int j = 0; j < 9; j++)
           for (int k = j; k < 9; k++) { L[j * 9 + k] = LtL[q]; L[k * 9 + j] = LtL[q]; q++; }
-        gl_jacobi_eigen(L, 9, W, V);
+        gl_ldsd* Wl = (gl_ldsd*)(s_mat + 2 * 144);   // 9 of the 16 doubles behind the two matrices
+        gl_jacobi_eigen9_lds((gl_ldsd*)L, Wl, (gl_ldsd*)V);
+        for (int i = 0; i < 9; i++) W[i] = Wl[i];
         double invHnorm[9] = {1. / smx, 0, c4[0], 0, 1. / smy, c4[1], 0, 0, 1};
         double Hnorm2[9] = {sMx, 0, -c4[2] * sMx, 0, sMy, -c4[3] * sMy, 0, 0, 1};
         double Htemp[9], H0[9];
@@ -878,8 +880,12 @@ int geom_pnp(mvo_ctx* ctx, int nslots, const float* obj, const float* img, const
   if (!st) st = ctx->stream;
   ModelParams P{};
   P.cam = make_camk(K, dist5);
-  launch_ransac<PnPModel>(ctx, st, nslots, obj, img, ctx->maxpts * 3, ctx->maxpts * 2, d_n, (double)reproj, conf, iters, P, mask, ctx->maxpts,
-                          model, result);
+  {
+    ProfScope ps(ctx, "pnp_ransac", st);
+    launch_ransac<PnPModel>(ctx, st, nslots, obj, img, ctx->maxpts * 3, ctx->maxpts * 2, d_n, (double)reproj, conf, iters, P, mask, ctx->maxpts,
+                            model, result);
+  }
+  ProfScope ps2(ctx, "pnp_refine", st);
   hipLaunchKernelGGL(mask_to_indices_kernel, dim3(nslots), dim3(1024), 0, st, mask, ctx->maxpts, d_n, inl, ctx->maxpts, result);
   PnpRefineArgs R;
   R.obj = obj; R.img = img; R.stride_pts = ctx->maxpts; R.inl = inl; R.result = result; R.model = model; R.n = d_n; R.pose = pose; R.cam = P.cam;

@@ -125,6 +125,144 @@ __device__ GL_NOINLINE void gl_jacobi_eigen(double* A, int n, double* W, double*
   }
 }
 
+// cv::eigen of a 9 x 9 symmetric matrix held in LDS (the homography minimal solver's LtL) - the same JacobiImpl_ rotation
+// sequence as gl_jacobi_eigen, value for value, restructured for one lane's instruction-level parallelism: a rotation
+// touches 7 element pairs of A and 9 of V that are independent of each other, so all 32 operands are requested before the
+// first is used (one LDS latency per rotation instead of sixteen dependent ones), the pivot search reads its 16
+// candidates the same way, and the indR / indC entries of the two rotated rows come from the freshly rotated values in
+// registers - they ARE rows / columns k and l - instead of being re-read.  Loops run over the static range 0..8 with
+// predicates, so the per-lane index arrays stay in registers (no scratch).  A: upper triangle used, destroyed.
+typedef __attribute__((address_space(3))) double gl_ldsd;
+__device__ GL_NOINLINE void gl_jacobi_eigen9_lds(gl_ldsd* A, gl_ldsd* W, gl_ldsd* V) {
+  constexpr int n = 9;
+  const double eps = DBL_EPSILON;
+  int indR[n], indC[n];
+#pragma unroll
+  for (int i = 0; i < n * n; i++) V[i] = 0;
+#pragma unroll
+  for (int i = 0; i < n; i++) V[i * n + i] = 1;
+#pragma unroll
+  for (int k = 0; k < n; k++) {
+    W[k] = A[(n + 1) * k];
+    indR[k] = 0; indC[k] = 0;
+    if (k < n - 1) {
+      int m = k + 1;
+      double mv = fabs(A[n * k + m]);
+#pragma unroll
+      for (int i = k + 2; i < n; i++) { const double val = fabs(A[n * k + i]); if (mv < val) mv = val, m = i; }
+      indR[k] = m;
+    }
+    if (k > 0) {
+      int m = 0;
+      double mv = fabs(A[k]);
+#pragma unroll
+      for (int i = 1; i < k; i++) { const double val = fabs(A[n * i + k]); if (mv < val) mv = val, m = i; }
+      indC[k] = m;
+    }
+  }
+  const int maxIters = n * n * 30;
+  int iters = 0;
+#pragma unroll 1
+  for (; iters < maxIters; iters++) {
+    // ---- pivot: largest |A[i][indR[i]]|, then |A[indC[i]][i]|, first maximum wins (strict <).  Everything below is
+    // written with selects: a branch per predicate made the loop body ~1500 instructions long ------------------------
+    double pr[n - 1], pc[n - 1];
+#pragma unroll
+    for (int i = 0; i < n - 1; i++) pr[i] = A[n * i + indR[i]];
+#pragma unroll
+    for (int i = 1; i < n; i++) pc[i - 1] = A[n * indC[i] + i];
+    int k = 0, l = indR[0];
+    double p = pr[0], mv = fabs(pr[0]);
+#pragma unroll
+    for (int i = 1; i < n - 1; i++) {
+      const double val = fabs(pr[i]);
+      const bool tk = mv < val;
+      mv = tk ? val : mv; k = tk ? i : k; l = tk ? indR[i] : l; p = tk ? pr[i] : p;
+    }
+#pragma unroll
+    for (int i = 1; i < n; i++) {
+      const double val = fabs(pc[i - 1]);
+      const bool tk = mv < val;
+      mv = tk ? val : mv; k = tk ? indC[i] : k; l = tk ? i : l; p = tk ? pc[i - 1] : p;
+    }
+    if (fabs(p) <= eps) break;
+    const double Wk = W[k], Wl = W[l];
+    // ---- the 16 independent element pairs: (A[up(i,k)], A[up(i,l)]) and (V[k][i], V[l][i]); loads first ---------------
+    int a0i[n], a1i[n];
+    double a0[n], a1[n], v0[n], v1[n];
+#pragma unroll
+    for (int i = 0; i < n; i++) {
+      a0i[i] = i < k ? n * i + k : n * k + i;
+      a1i[i] = i < l ? n * i + l : n * l + i;
+      a0[i] = A[a0i[i]]; a1[i] = A[a1i[i]];
+    }
+#pragma unroll
+    for (int i = 0; i < n; i++) { v0[i] = V[n * k + i]; v1[i] = V[n * l + i]; }
+    const double y = (Wl - Wk) * 0.5;
+    double t = fabs(y) + gl_hypot(p, y);
+    double s = gl_hypot(p, t);
+    const double c = t / s;
+    s = p / s;
+    t = (p / t) * p;
+    const bool neg = y < 0;
+    s = neg ? -s : s; t = neg ? -t : t;
+    W[k] = Wk - t;
+    W[l] = Wl + t;
+    // i == k addresses (A[k][k], A[k][l]) and i == l addresses (A[k][l], A[l][l]): the diagonal entries are dead (W holds
+    // the diagonal) and keep their value, A[k][l] becomes 0 - so every store is unconditional
+#pragma unroll
+    for (int i = 0; i < n; i++) {
+      const double x0 = a0[i], x1 = a1[i];
+      const double r0 = x0 * c - x1 * s, r1 = x0 * s + x1 * c;
+      a0[i] = i == k ? x0 : (i == l ? 0.0 : r0);
+      a1[i] = i == k ? 0.0 : (i == l ? x1 : r1);
+      A[a0i[i]] = a0[i]; A[a1i[i]] = a1[i];
+    }
+#pragma unroll
+    for (int i = 0; i < n; i++) {
+      const double x0 = v0[i], x1 = v1[i];
+      V[n * k + i] = x0 * c - x1 * s; V[n * l + i] = x0 * s + x1 * c;
+    }
+    // ---- indR / indC of rows k and l from the values just stored: row k = a0[i > k] (0 at i = l), column k = a0[i < k],
+    // row l = a1[i > l], column l = a1[i < l] (0 at i = k).  "first element initialises, then strict <" as the scans do
+    {
+      int mRk = 0, mCk = 0, mRl = 0, mCl = 0;
+      double vRk = 0, vCk = 0, vRl = 0, vCl = 0;
+      bool hRk = false, hCk = false, hRl = false, hCl = false;
+#pragma unroll
+      for (int i = 0; i < n; i++) {
+        const double f0 = fabs(a0[i]), f1 = fabs(a1[i]);
+        const bool gk = i > k, lk = i < k, gl = i > l, ll = i < l;
+        const bool tRk = gk & (!hRk | (vRk < f0)), tCk = lk & (!hCk | (vCk < f0));
+        const bool tRl = gl & (!hRl | (vRl < f1)), tCl = ll & (!hCl | (vCl < f1));
+        vRk = tRk ? f0 : vRk; mRk = tRk ? i : mRk; hRk |= gk;
+        vCk = tCk ? f0 : vCk; mCk = tCk ? i : mCk; hCk |= lk;
+        vRl = tRl ? f1 : vRl; mRl = tRl ? i : mRl; hRl |= gl;
+        vCl = tCl ? f1 : vCl; mCl = tCl ? i : mCl; hCl |= ll;
+      }
+#pragma unroll
+      for (int i = 0; i < n; i++) {
+        indR[i] = (i == k && k < n - 1) ? mRk : ((i == l && l < n - 1) ? mRl : indR[i]);
+        indC[i] = (i == k && k > 0) ? mCk : (i == l ? mCl : indC[i]);
+      }
+    }
+  }
+#ifdef RS_TIMING
+  if (threadIdx.x == 0 && blockIdx.x == 0) printf("eigen9 rotations %d\n", iters);
+#endif
+  // sort eigenvalues descending, rows of V follow (selection sort as in JacobiImpl_)
+#pragma unroll 1
+  for (int k = 0; k < n - 1; k++) {
+    int m = k;
+    for (int i = k + 1; i < n; i++)
+      if (W[m] < W[i]) m = i;
+    if (k != m) {
+      const double wk = W[k]; W[k] = W[m]; W[m] = wk;
+      for (int i = 0; i < n; i++) { const double t = V[n * m + i]; V[n * m + i] = V[n * k + i]; V[n * k + i] = t; }
+    }
+  }
+}
+
 // Second half of JacobiSVDImpl_: singular values, descending sort (rows of At / Vt follow), unit left vectors, and the
 // seeded Gram-Schmidt completion for vanishing singular values.  W: squared row norms are NOT needed, it is recomputed.
 // want_u with Vt == nullptr: the caller only reads the left vectors (EPnP's cvSVD(MtM, D, Ut, 0)).  The reference

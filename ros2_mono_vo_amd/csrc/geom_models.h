@@ -52,6 +52,9 @@ struct HModel {
   // runKernel for `count` float points (count = 4 inside RANSAC)
   __device__ GL_NOINLINE static int solve_n(const float* M, const float* m, int count, double* model, double* ws) {
     double *LtL = ws, *W = ws + 81, *V = ws + 90;
+#ifdef RS_TIMING
+    const long long tq0 = wall_clock64();
+#endif
     double cMx = 0, cMy = 0, cmx = 0, cmy = 0, sMx = 0, sMy = 0, smx = 0, smy = 0;
     for (int i = 0; i < count; i++) {
       cmx += m[2 * i]; cmy += m[2 * i + 1];
@@ -85,12 +88,26 @@ struct HModel {
     for (int j = 0; j < 9; j++)
 #pragma unroll 1
       for (int k = 0; k < j; k++) LtL[j * 9 + k] = LtL[k * 9 + j];
-    gl_jacobi_eigen(LtL, 9, W, V);
+#ifdef RS_TIMING
+    const long long tq1 = wall_clock64();
+#endif
+    // in the RANSAC kernel the workspace is LDS: the load-batched routine (same rotations, same values)
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__builtin_amdgcn_is_shared(ws)) gl_jacobi_eigen9_lds((gl_ldsd*)LtL, (gl_ldsd*)W, (gl_ldsd*)V);
+    else
+#endif
+      gl_jacobi_eigen(LtL, 9, W, V);
+#ifdef RS_TIMING
+    const long long tq2 = wall_clock64();
+#endif
     double Htemp[9], H0[9];
     gl_mat3mul(invHnorm, V + 72, Htemp);
     gl_mat3mul(Htemp, Hnorm2, H0);
     double s = 1. / H0[8];
     for (int i = 0; i < 9; i++) model[i] = H0[i] * s;
+#ifdef RS_TIMING
+    if (threadIdx.x == 0 && blockIdx.x == 0) printf("H solve: build %lld eigen %lld tail %lld ticks\n", tq1 - tq0, tq2 - tq1, wall_clock64() - tq2);
+#endif
     return 1;
   }
   __device__ static int solve(const ModelParams&, const float* ms1, const float* ms2, double* models, double* ws) {
