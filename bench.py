@@ -6,7 +6,7 @@ stream taking ITS OWN branch on the device (mvo_batch_track, csrc/track.hip): LK
 solvePnPRansac -> should_add_keyframe -> [findHomography + findFundamentalMat -> has_parallax -> [ORB + knn2/ratio match +
 triangulate + landmark hand-over]].  Streams are DISTINCT rendered 1280x720 scenes with true parallax (synth_gpu: own
 billboard layout, trajectory and noise per stream), 2000 ORB features, seeded with landmarks from the renderer's depth.
-Per GPU: C contexts x B streams (default 4 x 128), stepped asynchronously so that the one-wavefront-per-stream RANSAC
+Per GPU: C contexts x B streams (default 3 x 256), stepped asynchronously so that the one-wavefront-per-stream RANSAC
 chains of one context run beside the wide LK / ORB kernels of another; contexts start 0..10 frames apart so that their
 key-frame steps (every 11th frame under the reference's policy) do not coincide.
 
@@ -48,8 +48,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--contexts", type=int, default=4, help="contexts per GPU, stepped asynchronously")
-    ap.add_argument("--batch", type=int, default=128, help="independent camera streams per context")
+    ap.add_argument("--contexts", type=int, default=3, help="contexts per GPU, stepped asynchronously")
+    ap.add_argument("--batch", type=int, default=256, help="independent camera streams per context")
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--nfeatures", type=int, default=2000)
@@ -179,7 +179,7 @@ def main():
     # frames of the ingest phase go to pinned host memory; CPU-oracle streams are downloaded; then the device copy is dropped
     cpu_n = 0
     if not args.no_cpu_baseline and rank == 0:
-        cpu_n = min(B, args.cpu_streams if args.cpu_streams is not None else (os.cpu_count() or 1))
+        cpu_n = min(B, args.cpu_streams if args.cpu_streams is not None else min(os.cpu_count() or 1, 64))
     cpu_frames = frames[0, :1 + offs[0] + n_main, :cpu_n, :, :W].permute(1, 0, 2, 3).contiguous().cpu().numpy() if cpu_n else None
     if args.dump_stream is not None and rank == 0:
         np.savez_compressed(args.dump_path, frames=frames[0, :1 + n_main, args.dump_stream, :, :W].cpu().numpy(),

@@ -73,15 +73,22 @@ static void run(unsigned* d_out, long long* d_cyc, std::vector<long long>& h) {
   for (int wps : {1, 2, 4, 8}) {
     const int blocks = 256 * wps;   // 256 CUs x wps workgroups of 4 wavefronts (one per SIMD)
     hipLaunchKernelGGL((bench<OP, CH>), dim3(blocks), dim3(256), 0, 0, d_out, d_cyc, 12345u);
+    hipEvent_t ea, eb;
+    CK(hipEventCreate(&ea)); CK(hipEventCreate(&eb));
+    CK(hipEventRecord(ea));
     hipLaunchKernelGGL((bench<OP, CH>), dim3(blocks), dim3(256), 0, 0, d_out, d_cyc, 12345u);
+    CK(hipEventRecord(eb));
     CK(hipDeviceSynchronize());
+    float wall_ms = 0;
+    CK(hipEventElapsedTime(&wall_ms, ea, eb));
     CK(hipMemcpy(h.data(), d_cyc, (size_t)blocks * 4 * sizeof(long long), hipMemcpyDeviceToHost));
     double s = 0;
     for (int i = 0; i < blocks * 4; i++) s += (double)h[i];
     const double per_wave = s / (blocks * 4);
     const double ninst = (double)ITER * UNR * CH * per_it;
     // all wps waves of a SIMD run concurrently for about per_wave cycles and issue wps * ninst instructions
-    printf("  %dw/SIMD %6.2f (SIMD %5.2f)", wps, per_wave / ninst, per_wave / ninst / wps);
+    // wall clock: every SIMD issues wps * ninst instructions during the launch -> ns per wave-instruction per SIMD
+    printf("  %dw %6.2f (SIMD %5.2f tick, %5.2f ns)", wps, per_wave / ninst, per_wave / ninst / wps, wall_ms * 1e6 / (ninst * wps));
   }
   printf("\n");
 }

@@ -440,6 +440,13 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
   auto ptM = [&](int i, double M[3]) { int id = inl[i]; M[0] = obj[3 * id]; M[1] = obj[3 * id + 1]; M[2] = obj[3 * id + 2]; };
   auto ptm = [&](int i, double m[2]) { int id = inl[i]; m[0] = img[2 * id]; m[1] = img[2 * id + 1]; };
 
+#ifdef RS_TIMING
+  long long pt[6] = {0, 0, 0, 0, 0, 0};
+  long long pq = wall_clock64();
+#define PR_TICK(k) { long long tn = wall_clock64(); pt[k] += tn - pq; pq = tn; }
+#else
+#define PR_TICK(k)
+#endif
   double param[6] = {0, 0, 0, 0, 0, 0};
   // ---- Mc, MM ------------------------------------------------------------------------------------------------
   double acc[78];
@@ -596,6 +603,7 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
         for (int b = a; b < 12; b++) acc[q++] += l0[a] * l0[b] + l1[a] * l1[b];
     }
     block_sum<78, PR_NW>(acc, s_red, LL);
+    PR_TICK(0)
     if (tid == 0) {
       double* L = s_mat;
       double* LV = s_mat + 144;
@@ -631,6 +639,7 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
   if (!s_flag[1]) { if (tid == 0) result[6] = 0; return; }
   for (int i = 0; i < 6; i++) param[i] = s_sh[i];
   __syncthreads();
+  PR_TICK(1)
 
   // ---- CvLevMarq (J + err mode), state machine replicated by every lane, solves on lane 0 --------------------
   enum { DONE = 0, STARTED = 1, CALC_J = 2, CHECK_ERR = 3 };
@@ -654,6 +663,7 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
     __syncthreads();
     for (int i = 0; i < 6; i++) param[i] = s_sh[i];
     __syncthreads();
+    PR_TICK(2)
   };
   auto eval = [&](bool withJ) {
     double R[9], dRdr[27];
@@ -685,6 +695,10 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
       block_sum<1, PR_NW>(v + 27, s_red, o);
       curErr2 = o[0];
     }
+    PR_TICK(3)
+#ifdef RS_TIMING
+    pt[withJ ? 4 : 5] += 1;
+#endif
   };
   for (;;) {
     bool wantJ = false, wantErr = false, proceed;
@@ -726,6 +740,9 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
     for (int i = 0; i < 6; i++) pose[i] = param[i];
     result[6] = 1;
   }
+#ifdef RS_TIMING
+  if (tid == 0 && slot < 2) printf("PR_TIMING slot=%d n=%d planar=%d | sums %lld init-solve %lld lm-solve %lld lm-eval %lld | evalJ %lld evalErr %lld iters %d (100MHz ticks)\n", slot, count, (int)planar, pt[0], pt[1], pt[2], pt[3], pt[4], pt[5], iters);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------

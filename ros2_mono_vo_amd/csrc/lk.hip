@@ -177,8 +177,11 @@ __device__ __forceinline__ long long wave_sum_exact(int v) {
 // overflow: |v| < 2^28 lets groups of 8 lanes (3 steps) be summed in int32, |v| < 2^27 groups of 16 (4 steps); only
 // the remaining steps run on the hi / lo halves.  Bounds used by the callers: |J - I| <= 8160 and |Ix|, |Iy| <= 4080
 // (u8 image, 14-bit weights, 5 extra fractional bits; Scharr taps sum to 16), 7 pixels per lane.
+// The callers turn the sum into a float: (float)(sum * cn).  hi * 65536 + lo is exact in a double (|sum| < 2^47) and so is
+// the product with cn, and v_cvt_f32_f64 rounds to nearest even exactly like the int64 -> float conversion: same float,
+// five VALU instructions instead of the ~25 SALU instructions of the 64-bit integer path.
 template <int PLAIN>
-__device__ __forceinline__ long long wave_sum_exact_bounded(int v) {
+__device__ __forceinline__ double wave_sum_exact_bounded(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
   v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
   v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);  // row_half_mirror: groups of 8
@@ -192,7 +195,7 @@ __device__ __forceinline__ long long wave_sum_exact_bounded(int v) {
   hi += __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xA, 0xF, true);
   lo += __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xC, 0xF, true);  // row_bcast:31
   hi += __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xC, 0xF, true);
-  return (long long)__builtin_amdgcn_readlane(hi, 63) * 65536LL + (long long)__builtin_amdgcn_readlane(lo, 63);
+  return (double)__builtin_amdgcn_readlane(hi, 63) * 65536.0 + (double)__builtin_amdgcn_readlane(lo, 63);
 }
 
 __device__ __forceinline__ void lk_weights(float a, float b, int& w00, int& w01, int& w10, int& w11) {
@@ -242,9 +245,20 @@ __device__ __forceinline__ int lk_load_tile(unsigned* lds, const u8* __restrict_
 // as 3 dwords each and re-aligned with v_alignbyte.  v_perm builds the eight VERTICAL pairs V_k = (row0[k], row1[k])
 // as 16-bit lanes - neighbouring pixels share them - and two v_dot2c_i32_i16 per pixel, V_k . (w00, w10) +
 // V_k+1 . (w01, w11), evaluate the 4-tap fixed-point bilinear sum exactly.  Wa = w00 | w10 << 16, Wb = w01 | w11 << 16.
+// (a.lo * b.lo + a.hi * b.hi) + c on packed signed 16-bit pairs, three-operand form (no accumulator move)
+__device__ __forceinline__ int lk_dot2(unsigned a, unsigned b, int c) {
+  int r;
+  asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// low halves of two registers as one packed pair (lo, hi)
+__device__ __forceinline__ unsigned lk_pack16(int lo, int hi) { return __builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x05040100u); }
+
+// IxP / IyP: the lane's seven derivative values as packed pairs (0,1) (2,3) (4,5) (6,-): with the differences packed the same
+// way one v_dot2_i32_i16 accumulates two pixels of sum(diff * Ix) (|diff| <= 8160, |Ix|, |Iy| <= 4080: all fit 16 bits).
 template <bool ERR>
 __device__ __forceinline__ void lk_accumulate(const unsigned* jt, int byte_off, bool active, unsigned Wa, unsigned Wb, const int* Iv,
-                                              const int* Ixv, const int* Iyv, int& s1, int& s2) {
+                                              const unsigned* IxP, const unsigned* IyP, int& s1, int& s2) {
   s1 = 0; s2 = 0;
   if (!active) return;
   const int sh = byte_off & 3;
@@ -253,7 +267,7 @@ __device__ __forceinline__ void lk_accumulate(const unsigned* jt, int byte_off, 
   unsigned b0 = q[LK_JP / 4], b1 = q[LK_JP / 4 + 1], b2 = q[LK_JP / 4 + 2];
   unsigned r0lo = __builtin_amdgcn_alignbyte(a1, a0, sh), r0hi = __builtin_amdgcn_alignbyte(a2, a1, sh);
   unsigned r1lo = __builtin_amdgcn_alignbyte(b1, b0, sh), r1hi = __builtin_amdgcn_alignbyte(b2, b1, sh);
-  const lk_short2 wa = __builtin_bit_cast(lk_short2, Wa), wb = __builtin_bit_cast(lk_short2, Wb);
+  const lk_short2 wb = __builtin_bit_cast(lk_short2, Wb);
   lk_short2 V[8];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -261,16 +275,22 @@ __device__ __forceinline__ void lk_accumulate(const unsigned* jt, int byte_off, 
     V[k] = __builtin_bit_cast(lk_short2, __builtin_amdgcn_perm(r1lo, r0lo, sel));
     V[4 + k] = __builtin_bit_cast(lk_short2, __builtin_amdgcn_perm(r1hi, r0hi, sel));
   }
-#define LK_PIX(k)                                                                                                   \
-  {                                                                                                                 \
-    int acc = __builtin_amdgcn_sdot2(V[k], wa, Iv[k], false);                                                       \
-    acc = __builtin_amdgcn_sdot2(V[(k) + 1], wb, acc, false);                                                       \
-    int diff = acc >> 9;   /* Iv[k] = 256 - 512 * I:  ((J + 256) >> 9) - I == (J + 256 - 512 * I) >> 9 exactly */  \
-    if (ERR) { s1 += abs(diff); }                                                                                   \
-    else { s1 += __mul24(diff, Ixv[k]); s2 += __mul24(diff, Iyv[k]); }                                              \
+  int diff[7];
+#pragma unroll
+  for (int k = 0; k < 7; k++) {
+    int acc = lk_dot2(__builtin_bit_cast(unsigned, V[k]), Wa, Iv[k]);
+    acc = __builtin_amdgcn_sdot2(V[k + 1], wb, acc, false);
+    diff[k] = acc >> 9;   // Iv[k] = 256 - 512 * I:  ((J + 256) >> 9) - I == (J + 256 - 512 * I) >> 9 exactly
   }
-  LK_PIX(0) LK_PIX(1) LK_PIX(2) LK_PIX(3) LK_PIX(4) LK_PIX(5) LK_PIX(6)
-#undef LK_PIX
+  if (ERR) {
+#pragma unroll
+    for (int k = 0; k < 7; k++) s1 += abs(diff[k]);
+  } else {
+    const unsigned d01 = lk_pack16(diff[0], diff[1]), d23 = lk_pack16(diff[2], diff[3]), d45 = lk_pack16(diff[4], diff[5]);
+    const unsigned d6 = (unsigned)diff[6] & 0xFFFFu;
+    s1 = lk_dot2(d01, IxP[0], lk_dot2(d23, IxP[1], lk_dot2(d45, IxP[2], lk_dot2(d6, IxP[3], 0))));
+    s2 = lk_dot2(d01, IyP[0], lk_dot2(d23, IyP[1], lk_dot2(d45, IyP[2], lk_dot2(d6, IyP[3], 0))));
+  }
 }
 
 __device__ __forceinline__ void lk_track_point(const LkArgs& A, LkWaveLds& S, const int slot, const int p, const int lane) {
@@ -367,7 +387,8 @@ __device__ __forceinline__ void lk_track_point(const LkArgs& A, LkWaveLds& S, co
     // the low / high halves of two vertically adjacent entries give the dx / dy pairs.
     int w00, w01, w10, w11;
     lk_weights(px - ipx, py - ipy, w00, w01, w10, w11);
-    int Iv[7], Ixv[7], Iyv[7];
+    int Iv[7];
+    unsigned IxP[4], IyP[4];   // (Ix, Iy) of the lane's 7 pixels as packed 16-bit pairs (0,1) (2,3) (4,5) (6,-)
     int a11 = 0, a12 = 0, a22 = 0;
     if (active) {
       const lk_short2 wa = __builtin_bit_cast(lk_short2, (unsigned)w00 | ((unsigned)w10 << 16));
@@ -402,24 +423,33 @@ __device__ __forceinline__ void lk_track_point(const LkArgs& A, LkWaveLds& S, co
         XV[i] = __builtin_bit_cast(lk_short2, __builtin_amdgcn_perm(e1, e0, 0x05040100u));
         YV[i] = __builtin_bit_cast(lk_short2, __builtin_amdgcn_perm(e1, e0, 0x07060302u));
       }
+      int ixv[7], iyv[7];
 #pragma unroll
       for (int i = 0; i < 7; i++) {
         int ix = __builtin_amdgcn_sdot2(XV[i], wa, 0, false);
-        ix = descale(__builtin_amdgcn_sdot2(XV[i + 1], wb, ix, false), 14);
+        ixv[i] = descale(__builtin_amdgcn_sdot2(XV[i + 1], wb, ix, false), 14);
         int iy = __builtin_amdgcn_sdot2(YV[i], wa, 0, false);
-        iy = descale(__builtin_amdgcn_sdot2(YV[i + 1], wb, iy, false), 14);
-        Ixv[i] = ix; Iyv[i] = iy;
-        a11 += __mul24(ix, ix); a12 += __mul24(ix, iy); a22 += __mul24(iy, iy);
+        iyv[i] = descale(__builtin_amdgcn_sdot2(YV[i + 1], wb, iy, false), 14);
+      }
+#pragma unroll
+      for (int j = 0; j < 3; j++) { IxP[j] = lk_pack16(ixv[2 * j], ixv[2 * j + 1]); IyP[j] = lk_pack16(iyv[2 * j], iyv[2 * j + 1]); }
+      IxP[3] = (unsigned)ixv[6] & 0xFFFFu; IyP[3] = (unsigned)iyv[6] & 0xFFFFu;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {   // sum(ix * ix) etc. two pixels per instruction; exact integers either way
+        a11 = lk_dot2(IxP[j], IxP[j], a11); a12 = lk_dot2(IxP[j], IyP[j], a12); a22 = lk_dot2(IyP[j], IyP[j], a22);
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 7; i++) { Iv[i] = 256; Ixv[i] = 0; Iyv[i] = 0; }
+      for (int i = 0; i < 7; i++) Iv[i] = 256;
+#pragma unroll
+      for (int j = 0; j < 4; j++) { IxP[j] = 0u; IyP[j] = 0u; }
     }
     // per lane: 7 * 4080^2 < 2^27
-    long long sA11 = wave_sum_exact_bounded<4>(a11), sA12 = wave_sum_exact_bounded<4>(a12), sA22 = wave_sum_exact_bounded<4>(a22);
-    float A11 = (float)(sA11 * A.cn) * FLT_SCALE;
-    float A12 = (float)(sA12 * A.cn) * FLT_SCALE;
-    float A22 = (float)(sA22 * A.cn) * FLT_SCALE;
+    const double cnd = (double)A.cn;
+    const double sA11 = wave_sum_exact_bounded<4>(a11), sA12 = wave_sum_exact_bounded<4>(a12), sA22 = wave_sum_exact_bounded<4>(a22);
+    float A11 = (float)(sA11 * cnd) * FLT_SCALE;
+    float A12 = (float)(sA12 * cnd) * FLT_SCALE;
+    float A22 = (float)(sA22 * cnd) * FLT_SCALE;
     float D = A11 * A22 - A12 * A12;
     float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) /
                    (float)(2 * LK_WIN * LK_WIN);
@@ -451,10 +481,10 @@ __device__ __forceinline__ void lk_track_point(const LkArgs& A, LkWaveLds& S, co
       lk_weights(nx - inx, ny - iny, w00, w01, w10, w11);
       int s1, s2;
       lk_accumulate<false>(S.jt, (r + ddy) * LK_JP + x0 + ddx + shJ, active, (unsigned)w00 | ((unsigned)w10 << 16),
-                           (unsigned)w01 | ((unsigned)w11 << 16), Iv, Ixv, Iyv, s1, s2);
-      long long sb1 = wave_sum_exact_bounded<3>(s1), sb2 = wave_sum_exact_bounded<3>(s2);  // per lane: 7 * 8160 * 4080 < 2^28
-      float b1 = (float)(sb1 * A.cn) * FLT_SCALE;
-      float b2 = (float)(sb2 * A.cn) * FLT_SCALE;
+                           (unsigned)w01 | ((unsigned)w11 << 16), Iv, IxP, IyP, s1, s2);
+      const double sb1 = wave_sum_exact_bounded<3>(s1), sb2 = wave_sum_exact_bounded<3>(s2);  // per lane: 7 * 8160 * 4080 < 2^28
+      float b1 = (float)(sb1 * cnd) * FLT_SCALE;
+      float b2 = (float)(sb2 * cnd) * FLT_SCALE;
       float dx = (A12 * b2 - A22 * b1) * D;
       float dy = (A12 * b1 - A11 * b2) * D;
       nx += dx; ny += dy;
@@ -485,9 +515,9 @@ __device__ __forceinline__ void lk_track_point(const LkArgs& A, LkWaveLds& S, co
         lk_weights(ex - inx, ey - iny, w00, w01, w10, w11);
         int s1, s2;
         lk_accumulate<true>(S.jt, (r + ddy) * LK_JP + x0 + ddx + shJ, active, (unsigned)w00 | ((unsigned)w10 << 16),
-                            (unsigned)w01 | ((unsigned)w11 << 16), Iv, Ixv, Iyv, s1, s2);
-        long long se = (long long)wave_sum_i32_dpp(s1);  // 64 * 7 * 8160 fits 32 bits
-        float errval = (float)(se * A.cn);
+                            (unsigned)w01 | ((unsigned)w11 << 16), Iv, IxP, IyP, s1, s2);
+        const double se = (double)wave_sum_i32_dpp(s1);  // 64 * 7 * 8160 fits 32 bits
+        float errval = (float)(se * cnd);
         errv = errval * 1.f / (float)(32 * LK_WIN * A.cn * LK_WIN);
       }
     }
@@ -500,7 +530,12 @@ __device__ __forceinline__ void lk_track_point(const LkArgs& A, LkWaveLds& S, co
   }
 }
 
-__global__ __launch_bounds__(256) void lk_track_kernel(LkArgs A) {
+// Register budget: 6 wavefronts per SIMD (<= 80 VGPRs, no spills).  The kernel is a chain of dependent instructions per
+// wavefront (one tracked point), so resident wavefronts are what hides its latencies.
+#ifndef LK_WAVES_PER_EU
+#define LK_WAVES_PER_EU 6
+#endif
+__global__ __launch_bounds__(256, LK_WAVES_PER_EU) void lk_track_kernel(LkArgs A) {
   __shared__ LkWaveLds lds[4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   LkWaveLds& S = lds[wave];
@@ -568,9 +603,10 @@ int lk_track_device(mvo_ctx* ctx, int prev_set, int cur_set, const LkLevels& L, 
   A.eps2 = eps * eps;
   A.min_eig = ctx->cfg.lk_min_eig;
   if (d_work_slot) {
-    // persistent wavefronts: 5 workgroups of 4 per CU is what the kernel's registers allow (256 CUs)
+    // persistent wavefronts: LK_WAVES_PER_EU workgroups of 4 per CU is what the kernel's registers allow (256 CUs)
     const unsigned want = ((unsigned)nslots * (unsigned)ctx->maxpts + 4 * LK_CHUNK - 1) / (4 * LK_CHUNK);
-    hipLaunchKernelGGL(lk_track_kernel, dim3(want < 1280u ? want : 1280u), dim3(256), 0, st, A);
+    const unsigned full = 256u * LK_WAVES_PER_EU;
+    hipLaunchKernelGGL(lk_track_kernel, dim3(want < full ? want : full), dim3(256), 0, st, A);
     return MVO_OK;
   }
   if (max_n <= 0) return MVO_OK;
@@ -602,8 +638,17 @@ extern "C" int mvo_lk_track(mvo_ctx* ctx, const uint8_t* prev, const uint8_t* ne
   LkLevels L = lk_levels(w, h, ctx->cfg.lk_win, ctx->cfg.lk_max_level);
   int rc;
   ImgSet p0 = lk_imgset(ctx, 0, L, 0), c0 = lk_imgset(ctx, 1, L, 0);
-  if ((rc = upload_gray(ctx, prev, w, h, stride, channels, p0.base, p0.pitch, 0))) return rc;
-  if ((rc = upload_gray(ctx, next, w, h, stride, channels, c0.base, c0.pitch, 0))) return rc;
+  if ((rc = upload_gray(ctx, prev, w, h, stride, channels, p0.base, p0.pitch, 0, true))) return rc;
+  if ((rc = upload_gray(ctx, next, w, h, stride, channels, c0.base, c0.pitch, 0, true))) return rc;
+  if (channels != 1) {
+    int differ = 0;
+    if ((rc = color_channels_differ(ctx, &differ))) return rc;
+    if (differ) {
+      ctx->set_error("mvo_lk_track: true-colour input (channels differ) is not built: LK tracks one plane, which equals the "
+                     "reference's 3-channel LK only for mono8 replicated to BGR8; convert to mono8 or pass a replicated image");
+      return MVO_E_ARG;
+    }
+  }
   lk_build_pyramid(ctx, 0, L, 1);
   lk_build_pyramid(ctx, 1, L, 1);
   MVO_HIP(hipMemcpyAsync(ctx->d_prev_pts, prev_pts, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));

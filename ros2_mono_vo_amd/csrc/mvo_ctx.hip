@@ -59,18 +59,22 @@ LkLevels lk_levels(int w, int h, int win, int max_level) {
 // colour -> gray as the reference's ingest does it: cv_bridge::toCvShare(msg, BGR8) (src/mono_vo.cpp:94; rgb8 is a
 // channel swap, bgra8 / rgba8 drop alpha) followed by OpenCV's cvtColor(BGR2GRAY) inside ORB: RGB2Gray<uchar> with the
 // 15-bit weights BY15 = 3735, GY15 = 19235, RY15 = 9798.  `bpp` 3 or 4, `rgb` = red comes first.
+// `differ` (optional): set to 1 when any pixel's three channels are not identical.  LK callers need it: the reference runs
+// calcOpticalFlowPyrLK on the BGR8 image (src/mono_vo.cpp:94 -> src/tracker.cpp:68), i.e. its sums run over three channels; the
+// device tracks one plane and scales the sums by lk_channels, which equals the reference only for replicated mono8.
 __global__ void color2gray_kernel(const u8* __restrict__ src, int spitch, u8* __restrict__ dst, int dpitch, int w, int h, int bpp,
-                                  int rgb) {
+                                  int rgb, int* __restrict__ differ) {
   int x = blockIdx.x * blockDim.x + threadIdx.x;
   int y = blockIdx.y;
   if (x >= w) return;
   const u8* p = src + (size_t)y * spitch + bpp * x;
   const int b = rgb ? p[2] : p[0], g = p[1], r = rgb ? p[0] : p[2];
   dst[(size_t)y * dpitch + x] = (u8)((b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15);
+  if (differ && (b != g || g != r)) *differ = 1;   // benign race: every writer stores the same value
 }
 
 int upload_gray(mvo_ctx* ctx, const uint8_t* img, int w, int h, int stride, int channels, u8* d_dst,
-                int dpitch, int slot) {
+                int dpitch, int slot, bool check_identical) {
   if (channels == 1) {
     MVO_HIP(hipMemcpy2DAsync(d_dst, dpitch, img, stride, w, h, hipMemcpyDefault, ctx->stream));
   } else if (channels == 3 || channels == -3 || channels == 4 || channels == -4) {
@@ -79,7 +83,8 @@ int upload_gray(mvo_ctx* ctx, const uint8_t* img, int w, int h, int stride, int 
     int spitch = align_up(w * bpp, 64);
     MVO_HIP(hipMemcpy2DAsync(st, spitch, img, stride, (size_t)w * bpp, h, hipMemcpyDefault, ctx->stream));
     dim3 grid((w + 255) / 256, h);
-    hipLaunchKernelGGL(color2gray_kernel, grid, dim3(256), 0, ctx->stream, st, spitch, d_dst, dpitch, w, h, bpp, channels < 0 ? 1 : 0);
+    hipLaunchKernelGGL(color2gray_kernel, grid, dim3(256), 0, ctx->stream, st, spitch, d_dst, dpitch, w, h, bpp, channels < 0 ? 1 : 0,
+                       check_identical ? ctx->d_colorflag : nullptr);
   } else {
     ctx->set_error("channels must be 1 (mono8), 3 (BGR8), -3 (RGB8), 4 (BGRA8) or -4 (RGBA8)");
     return MVO_E_ARG;
@@ -125,6 +130,8 @@ static int mvo_create_impl(const mvo_config* cfg, mvo_ctx** out) {
   MVO_HIP(hipMalloc(&ctx->d_npts, ctx->B * sizeof(int)));
   ctx->stage_slot_bytes = (size_t)align_up(ctx->maxw * 4, 64) * ctx->maxh;
   MVO_HIP(hipMalloc(&ctx->d_stage, ctx->stage_slot_bytes * ctx->B));
+  MVO_HIP(hipMalloc(&ctx->d_colorflag, sizeof(int)));
+  MVO_HIP(hipMemset(ctx->d_colorflag, 0, sizeof(int)));
   ctx->h_pin_bytes = (size_t)16 << 20;
   MVO_HIP(hipHostMalloc(&ctx->h_pin, ctx->h_pin_bytes, hipHostMallocDefault));
   int rc;
@@ -164,9 +171,20 @@ extern "C" void mvo_destroy(mvo_ctx* ctx) {
   (void)hipFree(ctx->d_err);
   (void)hipFree(ctx->d_npts);
   (void)hipFree(ctx->d_stage);
+  (void)hipFree(ctx->d_colorflag);
   if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
+}
+
+// 1 if a colour upload since the last call had differing channels (waits for the stream); clears the flag
+int color_channels_differ(mvo_ctx* ctx, int* differ) {
+  int* h = (int*)ctx->h_pin;
+  MVO_HIP(hipMemcpyAsync(h, ctx->d_colorflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  MVO_HIP(hipMemsetAsync(ctx->d_colorflag, 0, sizeof(int), ctx->stream));
+  MVO_HIP(hipStreamSynchronize(ctx->stream));
+  *differ = h[0];
+  return MVO_OK;
 }
 
 extern "C" const char* mvo_last_error(const mvo_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }

@@ -56,6 +56,7 @@ struct mvo_ctx {
   int* d_npts = nullptr;        // [B]
 
   // ---- staging -------------------------------------------------------------------------------------
+  int* d_colorflag = nullptr;  // set by colour uploads whose channels differ (LK is built for replicated mono8 only)
   u8* d_stage = nullptr;  // raw upload staging (BGR or strided input), maxw*maxh*3 per slot
   size_t stage_slot_bytes = 0;
   u8* h_pin = nullptr;    // pinned host scratch
@@ -270,7 +271,8 @@ int geom_triangulate_matches(mvo_ctx* ctx, int nslots, int max_matches, const mv
 
 // Upload a host image (mono8 or BGR8, arbitrary stride) into a device mono8 ImgSet slot (async on ctx->stream).
 int upload_gray(mvo_ctx* ctx, const uint8_t* img, int w, int h, int stride, int channels, u8* d_dst,
-                int dpitch, int slot);
+                int dpitch, int slot, bool check_identical = false);
+int color_channels_differ(mvo_ctx* ctx, int* differ);   // see color2gray_kernel
 
 // ---- device helpers -------------------------------------------------------------------------------
 __device__ __forceinline__ int d_reflect101(int p, int len) {

@@ -345,7 +345,13 @@ extern "C" int mvo_batch_preload_frame(mvo_ctx* ctx, int slot, int frame_idx, co
   if (p->w == 0) { p->w = w; p->h = h; p->pitch = align_up(w, 64); }
   if (w != p->w || h != p->h) { ctx->set_error("all ring frames must share one size"); return MVO_E_ARG; }
   u8* dst = p->d_ring + ((size_t)frame_idx * ctx->B + slot) * p->frame_bytes;
-  return upload_gray(ctx, img, w, h, stride, channels, dst, p->pitch, slot);
+  int rc = upload_gray(ctx, img, w, h, stride, channels, dst, p->pitch, slot, true);
+  if (rc || channels == 1) return rc;
+  // the ring feeds LK: colour frames must be replicated mono8 (see color2gray_kernel)
+  int differ = 0;
+  if ((rc = color_channels_differ(ctx, &differ))) return rc;
+  if (differ) { ctx->set_error("mvo_batch_preload_frame: true-colour frames (channels differ) are not built for the tracker's LK"); return MVO_E_ARG; }
+  return MVO_OK;
 }
 
 static int pipe_load_frame(mvo_ctx* ctx, int frame_idx, int lk_set) {

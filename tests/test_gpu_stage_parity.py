@@ -235,3 +235,24 @@ def test_lk_edge_cases(ctx720, frames480):
     small = a[:101, :87]
     sp = np.array([[10, 10], [50, 50], [80, 95], [43.5, 20.25]], np.float32)
     _check_lk(ctx720, small, b[:101, :87], sp)
+
+
+def test_lk_colour_input_must_be_replicated_mono(ctx480, frames480):
+    """The reference tracks on the BGR8 image (src/mono_vo.cpp:94 -> src/tracker.cpp:68): three channels in every LK sum.  The
+    device tracks one plane with the sums scaled by lk_channels, which is the same thing only for mono8 replicated to BGR8
+    (then bit-exact vs the 3-channel oracle); true colour is refused instead of silently diverging."""
+    from ros2_mono_vo_amd import MvoError
+    a, b = frames480[0], frames480[1]
+    pts = np.stack([np.linspace(60, 580, 64), np.linspace(50, 430, 64)], 1).astype(np.float32)
+    rep = lambda g: np.stack([g, g, g], -1)
+    p3, s3, e3 = ctx480.lk_track(rep(a), rep(b), pts)
+    p1, s1, e1 = ctx480.lk_track(a, b, pts)
+    op, os_, oe = O.lk_track(a, b, pts, cn=3)
+    assert np.array_equal(p3, op) and np.array_equal(s3, os_) and np.array_equal(e3, oe)
+    assert np.array_equal(p1, p3) and np.array_equal(s1, s3) and np.array_equal(e1, e3)
+    col = rep(a).copy()
+    col[100, 100, 2] ^= 0x10                       # one pixel with differing channels
+    with pytest.raises(MvoError) as ei:
+        ctx480.lk_track(col, rep(b), pts)
+    assert ei.value.code == 1 and "true-colour" in str(ei.value)
+    ctx480.lk_track(rep(a), rep(b), pts)            # the flag does not stick
