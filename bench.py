@@ -53,7 +53,7 @@ def parse_args():
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--nfeatures", type=int, default=2000)
-    ap.add_argument("--ingest-steps", type=int, default=8, help="steps of the value_with_ingest phase (0 = skip)")
+    ap.add_argument("--ingest-steps", type=int, default=12, help="steps of the value_with_ingest phase (0 = skip)")
     ap.add_argument("--extra-steps", type=int, default=5, help="steps of the always-on and key-frame-every-frame phases (0 = skip)")
     ap.add_argument("--cpu-streams", type=int, default=None, help="streams checked against / timed on the CPU oracle (default: host cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -32,7 +32,7 @@ struct TrackState {
   int* d_nkf = nullptr;        // [1]
   int* d_pt_base = nullptr;    // [B+1] LK work list: first item of each slot
   int* d_work_slot = nullptr;  // [B*maxpts] LK work list: slot of each item
-  int* d_work_ctr = nullptr;   // [1]
+  int* d_work_ctr = nullptr;   // [8] claim counters of the LK work list, one per XCD part
   int* d_err = nullptr;        // [1] capacity flags raised on the device
   u8* d_mask_f = nullptr;      // [B][maxpts] F consensus mask (H uses geom->d_mask2)
   double* d_model_f = nullptr; // [B][16]
@@ -60,7 +60,8 @@ __global__ __launch_bounds__(1024) void trk_worklist_scan_kernel(const int* __re
   __shared__ int s_w[16];
   __shared__ int s_run;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) { s_run = 0; *work_ctr = 0; }
+  if (threadIdx.x == 0) s_run = 0;
+  if (threadIdx.x < 8) work_ctr[threadIdx.x] = 0;   // one claim counter per XCD part of the list (lk_track_kernel)
   __syncthreads();
   for (int s0 = 0; s0 < B; s0 += 1024) {
     const int s = s0 + threadIdx.x;
@@ -446,7 +447,7 @@ static int trk_create(mvo_ctx* ctx) {
   MVO_HIP(hipMalloc(&t->d_nkf, sizeof(int)));
   MVO_HIP(hipMalloc(&t->d_pt_base, (B + 1) * sizeof(int)));
   MVO_HIP(hipMalloc(&t->d_work_slot, np * sizeof(int)));
-  MVO_HIP(hipMalloc(&t->d_work_ctr, sizeof(int)));
+  MVO_HIP(hipMalloc(&t->d_work_ctr, 8 * sizeof(int)));
   MVO_HIP(hipMalloc(&t->d_err, sizeof(int)));
   MVO_HIP(hipMalloc(&t->d_mask_f, np));
   MVO_HIP(hipMalloc(&t->d_model_f, (size_t)B * 16 * sizeof(double)));
