@@ -180,3 +180,17 @@ def test_recover_pose(ctx720):
     # the three wrong candidates must lose: flipped E sign still recovers the same pose
     g2, R2, t2, _ = ctx720.recover_pose(-E, sc["p1"], sc["p2"], sc["K"], mask=m0)
     assert np.abs(R2 - sc["R"]).max() < 1e-9
+
+
+def test_forced_4096_hypotheses_f_and_pnp(ctx720):
+    """C4 (LDS-pressure config): 4096 hypotheses with the adaptive stop disabled (confidence ~ 1), for F and PnP as well as H
+    (test_ransac_edge_cases): iteration counts, masks / inlier lists identical to the sequential oracle."""
+    sc = scene(4000)
+    ok, mask, F, ni = ctx720.find_fundamental_ransac(sc["p1"], sc["p2"], 1.0, 1 - 1e-15, 4096)
+    r, omask, oF, st = O.find_fundamental_ransac(sc["p1"], sc["p2"], 1.0, 1 - 1e-15, 4096)
+    assert st[0] == 4096 and ok == (r > 0) and ni == r and np.array_equal(mask, omask)
+    assert np.abs(F - oF).max() <= 1e-12 * max(1.0, np.abs(oF).max())
+    ok, rv, tv, idx = ctx720.solve_pnp_ransac(sc["X"], sc["p2"], sc["K"], None, 4096, 8.0, 1 - 1e-15)
+    rc, orv, otv, oidx, st = O.solve_pnp_ransac(sc["X"], sc["p2"], sc["K"], None, 4096, 8.0, 1 - 1e-15)
+    assert st[0] == 4096 and ok and rc == 1 and np.array_equal(idx, oidx)
+    assert np.abs(rv - orv).max() <= 1e-9 and np.abs(tv - otv).max() <= 1e-9 * max(1.0, np.abs(otv).max())

@@ -1,0 +1,131 @@
+"""Property tests of SURVEY 4 item 4 (hypothesis): matcher ties / symmetry of the distance, LK zero motion => zero flow,
+RANSAC mask is a subset of the threshold set of its own model.  On the CPU they exercise the oracle; the `gpu` variants run
+the same properties through the C ABI on the HIP path."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+import oracle_py as O
+from ros2_mono_vo_amd import synth
+
+SET = dict(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+
+
+def hamming(a, b):
+    return int(np.unpackbits(np.bitwise_xor(a, b)).sum())
+
+
+def check_matches(m, q, t, ratio):
+    """Every reported match is the true nearest neighbour (ties -> lowest train index) and passes Lowe's test against the true
+    second neighbour; every query that passes is reported."""
+    D = np.array([[hamming(a, b) for b in t] for a in q]).reshape(len(q), len(t))
+    want = []
+    for i in range(len(q)):
+        if len(t) < 2:
+            continue
+        order = np.lexsort((np.arange(len(t)), D[i]))           # distance, then index
+        d0, d1 = D[i, order[0]], D[i, order[1]]
+        if float(np.float32(d0)) < ratio * float(np.float32(d1)):
+            want.append((i, int(order[0]), float(d0)))
+    got = [(int(a), int(b), float(c)) for a, b, c in zip(m["query_idx"], m["train_idx"], m["distance"])]
+    assert got == want
+
+
+desc = st.integers(0, 2**32 - 1).map(lambda s: np.random.default_rng(s))
+
+
+@given(seed=st.integers(0, 2**31), nq=st.integers(0, 12), nt=st.integers(0, 12), dup=st.booleans(), ratio=st.sampled_from([0.5, 0.7, 0.9, 1.0]))
+@settings(**SET)
+def test_matcher_ties_and_ratio_oracle(seed, nq, nt, dup, ratio):
+    rng = np.random.default_rng(seed)
+    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    if dup and nt >= 2:
+        t[nt // 2] = t[0]                                        # exact tie between two train rows
+    if dup and nq >= 1 and nt >= 1:
+        q[0] = t[0]                                              # distance 0
+    check_matches(O.match_knn2_ratio(q, t, ratio), q, t, ratio)
+
+
+@given(seed=st.integers(0, 2**31))
+@settings(max_examples=6, deadline=None)
+def test_lk_zero_motion_is_zero_flow_oracle(seed):
+    img = synth.gen_stream(160, 120, 0x5EED0900 + seed % 1000, 1)[0]
+    rng = np.random.default_rng(seed)
+    pts = np.stack([rng.uniform(5, 155, 40), rng.uniform(5, 115, 40)], 1).astype(np.float32)
+    nxt, status, err = O.lk_track(img, img, pts, cn=3)
+    good = status != 0
+    # nextPt is carried as (pt - halfWin) + halfWin in float, so the sub-pixel phase of a point can move by an ulp between
+    # levels: zero flow up to a rounding-sized residual (far below the 0.01 px stop criterion), residual error ~ 0
+    assert np.abs(nxt[good] - pts[good]).max() <= 1e-3 and np.all(err[good] <= 0.05) and good.sum() >= 20
+
+
+def check_ransac_subset(ok, mask, model, p1, p2, thr, kind):
+    if not ok:
+        assert mask.sum() == 0
+        return
+    p1 = p1.astype(np.float64); p2 = p2.astype(np.float64)
+    if kind == "H":
+        x = np.c_[p1, np.ones(len(p1))] @ model.T
+        e = ((x[:, :2] / x[:, 2:]) - p2) ** 2
+        err = e.sum(1)
+    else:
+        a = np.c_[p1, np.ones(len(p1))] @ model.T               # F x1: epipolar lines in image 2
+        b = np.c_[p2, np.ones(len(p2))] @ model                 # F^T x2
+        d2 = (np.c_[p2, np.ones(len(p2))] * a).sum(1)
+        err = np.maximum(d2 ** 2 / (a[:, 0] ** 2 + a[:, 1] ** 2), d2 ** 2 / (b[:, 0] ** 2 + b[:, 1] ** 2))
+    inside = err <= thr * thr * (1 + 1e-6) + 1e-9
+    assert not np.any((mask != 0) & ~inside)                     # mask is a subset of the threshold set
+    assert (mask != 0).sum() >= (4 if kind == "H" else 7)
+
+
+@given(seed=st.integers(0, 2**31), P=st.integers(20, 120), outl=st.sampled_from([0.0, 0.2, 0.5]), planar=st.booleans())
+@settings(**SET)
+def test_ransac_mask_subset_of_threshold_set_oracle(seed, P, outl, planar):
+    sc = synth.gen_scene(P, seed, planar=planar, outlier_frac=outl)
+    r, mask, H, _ = O.find_homography_ransac(sc["p1"], sc["p2"], 1.0)
+    check_ransac_subset(r > 0, mask, H, sc["p1"], sc["p2"], 1.0, "H")
+    r, mask, F, _ = O.find_fundamental_ransac(sc["p1"], sc["p2"], 1.0, 0.99)
+    if r != -2:                                                  # 8..14 points: LMedS, not a threshold mask
+        check_ransac_subset(r > 0, mask, F, sc["p1"], sc["p2"], 1.0, "F")
+
+
+# ---- the same properties on the HIP path ----------------------------------------------------------------------------------
+@pytest.mark.gpu
+@given(seed=st.integers(0, 2**31), nq=st.integers(0, 12), nt=st.integers(0, 12), dup=st.booleans(), ratio=st.sampled_from([0.5, 0.7, 0.9, 1.0]))
+@settings(**SET)
+def test_matcher_ties_and_ratio_hip(ctx480, seed, nq, nt, dup, ratio):
+    rng = np.random.default_rng(seed)
+    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    if dup and nt >= 2:
+        t[nt // 2] = t[0]
+    if dup and nq >= 1 and nt >= 1:
+        q[0] = t[0]
+    check_matches(ctx480.match_knn2_ratio(q, t, ratio), q, t, ratio)
+
+
+@pytest.mark.gpu
+@given(seed=st.integers(0, 2**31))
+@settings(max_examples=6, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+def test_lk_zero_motion_is_zero_flow_hip(ctx480, seed):
+    img = synth.gen_stream(160, 120, 0x5EED0900 + seed % 1000, 1)[0]
+    rng = np.random.default_rng(seed)
+    pts = np.stack([rng.uniform(5, 155, 40), rng.uniform(5, 115, 40)], 1).astype(np.float32)
+    nxt, status, err = ctx480.lk_track(img, img, pts)
+    good = status != 0
+    # nextPt is carried as (pt - halfWin) + halfWin in float, so the sub-pixel phase of a point can move by an ulp between
+    # levels: zero flow up to a rounding-sized residual (far below the 0.01 px stop criterion), residual error ~ 0
+    assert np.abs(nxt[good] - pts[good]).max() <= 1e-3 and np.all(err[good] <= 0.05) and good.sum() >= 20
+
+
+@pytest.mark.gpu
+@given(seed=st.integers(0, 2**31), P=st.integers(20, 120), outl=st.sampled_from([0.0, 0.2, 0.5]), planar=st.booleans())
+@settings(**SET)
+def test_ransac_mask_subset_of_threshold_set_hip(ctx480, seed, P, outl, planar):
+    sc = synth.gen_scene(P, seed, planar=planar, outlier_frac=outl)
+    ok, mask, H, _ = ctx480.find_homography_ransac(sc["p1"], sc["p2"], 1.0)
+    check_ransac_subset(ok, mask, H, sc["p1"], sc["p2"], 1.0, "H")
+    if not (8 <= P < 15):
+        ok, mask, F, _ = ctx480.find_fundamental_ransac(sc["p1"], sc["p2"], 1.0, 0.99)
+        check_ransac_subset(ok, mask, F, sc["p1"], sc["p2"], 1.0, "F")
