@@ -119,13 +119,9 @@ int pipe_state_create(mvo_ctx* ctx) {
   MVO_HIP(hipMalloc(&p->d_tri_ok, np));
   MVO_HIP(hipMalloc(&p->d_kf_pose, (size_t)ctx->B * 8 * sizeof(double)));
   MVO_HIP(hipMalloc(&p->d_ntri, ctx->B * sizeof(int)));
-  {
-    int prio_lo = 0, prio_hi = 0;  // numerically lower = higher priority
-    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    MVO_HIP(hipStreamCreateWithPriority(&p->s_lk, hipStreamNonBlocking, prio_hi));
-    MVO_HIP(hipStreamCreateWithPriority(&p->s_pnp, hipStreamNonBlocking, prio_hi));
-    MVO_HIP(hipStreamCreateWithFlags(&p->s_hf, hipStreamNonBlocking));
-  }
+  // the side streams of the stage-mask step (mvo_batch_step) are created on first use: HIP maps streams onto a few
+  // hardware queues (GPU_MAX_HW_QUEUES, 4 by default), and idle streams of several contexts were sharing - and
+  // serialising - the queues the device-driven step of other contexts runs on
   MVO_HIP(hipEventCreateWithFlags(&p->ev_frame, hipEventDisableTiming));
   MVO_HIP(hipEventCreateWithFlags(&p->ev_lktrack, hipEventDisableTiming));
   MVO_HIP(hipEventCreateWithFlags(&p->ev_lk, hipEventDisableTiming));
@@ -463,9 +459,21 @@ extern "C" int mvo_batch_set_landmarks(mvo_ctx* ctx, int slot, const float* xyz,
   return MVO_OK;
 }
 
+static int pipe_side_streams(mvo_ctx* ctx) {
+  PipeState* p = ctx->pipe;
+  if (p->s_lk) return MVO_OK;
+  int prio_lo = 0, prio_hi = 0;  // numerically lower = higher priority
+  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  MVO_HIP(hipStreamCreateWithPriority(&p->s_lk, hipStreamNonBlocking, prio_hi));
+  MVO_HIP(hipStreamCreateWithPriority(&p->s_pnp, hipStreamNonBlocking, prio_hi));
+  MVO_HIP(hipStreamCreateWithFlags(&p->s_hf, hipStreamNonBlocking));
+  return MVO_OK;
+}
+
 extern "C" int mvo_batch_step(mvo_ctx* ctx, int frame_idx, unsigned stages, mvo_step_result* out) {
   if (!ctx || !ctx->pipe || !out) return MVO_E_ARG;
   PipeState* p = ctx->pipe;
+  { int rcs = pipe_side_streams(ctx); if (rcs) return rcs; }
   MatchState* m = ctx->match;
   GeomState* g = ctx->geom;
   if (!p->seeded || frame_idx < 0 || frame_idx >= p->ring) { ctx->set_error("mvo_batch_step: not seeded / bad frame"); return MVO_E_ARG; }

@@ -21,6 +21,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 
 struct TrackState {
   int* d_state = nullptr;      // [B] MVO_TRACK_*
@@ -467,7 +468,8 @@ static int trk_create(mvo_ctx* ctx) {
 void trk_destroy(mvo_ctx* ctx) {
   PipeState* p = ctx->pipe;
   if (!p) return;
-  if (p->s_up) { (void)hipStreamSynchronize(p->s_up); (void)hipStreamDestroy(p->s_up); p->s_up = nullptr; }
+  if (p->s_up && !p->up_shared) { (void)hipStreamSynchronize(p->s_up); (void)hipStreamDestroy(p->s_up); }
+  p->s_up = nullptr;
   for (auto e : p->ev_up) (void)hipEventDestroy(e);
   for (auto e : p->ev_rd) (void)hipEventDestroy(e);
   p->ev_up.clear(); p->ev_rd.clear();
@@ -486,7 +488,9 @@ void trk_destroy(mvo_ctx* ctx) {
 static int trk_ring_events(mvo_ctx* ctx) {
   PipeState* p = ctx->pipe;
   if (!p->ev_up.empty()) return MVO_OK;
-  MVO_HIP(hipStreamCreateWithFlags(&p->s_up, hipStreamNonBlocking));
+  if (const char* e = getenv("MVO_UPLOAD_STREAM")) p->up_shared = atoi(e) == 0;   // 0: uploads go on the compute stream
+  if (p->up_shared) p->s_up = ctx->stream;
+  else MVO_HIP(hipStreamCreateWithFlags(&p->s_up, hipStreamNonBlocking));
   p->ev_up.resize(p->ring); p->ev_rd.resize(p->ring);
   p->up_pending.assign(p->ring, 0); p->rd_pending.assign(p->ring, 0);
   for (int i = 0; i < p->ring; i++) {
