@@ -162,3 +162,29 @@ def test_async_ingest_and_interleaved_contexts_match_the_synchronous_run():
     finally:
         for c in ctxs:
             c.close()
+
+
+def test_track_reproduces_the_committed_golden_vectors():
+    """mvo_batch_track against tests/golden/track_v1.json (made by make_track_golden.py from the oracle-driven reference
+    tracker): the fixtures, not a live oracle run, are the checker here."""
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "track_v1.json")))
+    N, kinds = gold["frames"], ("lateral", "cut")
+    K = synth.default_K(TS.W, TS.H)
+    data = [TS.stream(kind, N) for kind in kinds]
+    with Context(max_width=TS.W, max_height=TS.H, batch=2, nfeatures=1000, max_points=4096, ring_frames=N) as ctx:
+        ctx.batch_set_intrinsics(K)
+        for s in range(2):
+            for f in range(N):
+                ctx.batch_preload_frame(s, f, data[s][0][f])
+        ctx.batch_seed(0)
+        for s in range(2):
+            ctx.batch_set_landmarks(s, TS.depth_landmarks(K, data[s][1])(ctx.batch_get_tracks(s)))
+        for k in range(1, N):
+            out = ctx.batch_track(k)
+            for s, kind in enumerate(kinds):
+                g = gold[kind][k - 1]
+                assert [int(getattr(out[s], key)) for key in gold["keys"]] == g["ints"], (k, kind)
+                if g["ints"][gold["keys"].index("flags")] & _lib.STEP_POSE:
+                    assert np.abs(np.array(out[s].rvec) - g["rvec"]).max() < 1e-6 and np.abs(np.array(out[s].tvec) - g["tvec"]).max() < 1e-6
