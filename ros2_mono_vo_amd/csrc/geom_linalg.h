@@ -395,6 +395,9 @@ typedef __attribute__((address_space(3))) double gl_lds_double;
 __device__ __forceinline__ bool gl_is_lds(const void* p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __builtin_amdgcn_is_shared(p);
+#elif defined(GL_TEST_FORCE_LDS_PATH)   // x86 sanitizer harness (tests/sanitize): take the LDS-specialised routines too
+  (void)p;
+  return true;
 #else
   (void)p;
   return false;

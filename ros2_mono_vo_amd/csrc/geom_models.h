@@ -92,11 +92,8 @@ struct HModel {
     const long long tq1 = wall_clock64();
 #endif
     // in the RANSAC kernel the workspace is LDS: the load-batched routine (same rotations, same values)
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (__builtin_amdgcn_is_shared(ws)) gl_jacobi_eigen9_lds((gl_ldsd*)LtL, (gl_ldsd*)W, (gl_ldsd*)V);
-    else
-#endif
-      gl_jacobi_eigen(LtL, 9, W, V);
+    if (gl_is_lds(ws)) gl_jacobi_eigen9_lds((gl_ldsd*)LtL, (gl_ldsd*)W, (gl_ldsd*)V);
+    else gl_jacobi_eigen(LtL, 9, W, V);
 #ifdef RS_TIMING
     const long long tq2 = wall_clock64();
 #endif
