@@ -54,6 +54,7 @@ def parse_args():
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--nfeatures", type=int, default=2000)
     ap.add_argument("--ingest-steps", type=int, default=12, help="steps of the value_with_ingest phase (0 = skip)")
+    ap.add_argument("--ingest-ring", type=int, default=2, help="ring entries the ingest phase cycles through (uploads run ring - 1 frames ahead)")
     ap.add_argument("--extra-steps", type=int, default=5, help="steps of the always-on and key-frame-every-frame phases (0 = skip)")
     ap.add_argument("--cpu-streams", type=int, default=None, help="streams checked against / timed on the CPU oracle (default: host cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -195,6 +196,8 @@ def main():
     torch.cuda.empty_cache()
     t_setup = time.perf_counter() - t_setup
 
+    RING = max(2, args.ingest_ring)
+
     def run_phase(n_steps, first_frame, record=None, ingest=False):
         """Every context takes n_steps steps (its frames first_frame[c] ...), kept in flight independently: as soon as a
         context's step is collected its next one is enqueued.  -> elapsed seconds (barrier + device sync on both sides)."""
@@ -203,16 +206,17 @@ def main():
             dist.barrier()
         t0 = time.perf_counter()
         if ingest:
-            for c, ctx in enumerate(ctxs):
-                ctx.batch_upload_async(0, pins[c][0].ctypes.data, W, H, pitch, H * pitch)
+            for j in range(min(RING - 1, n_steps)):
+                for c, ctx in enumerate(ctxs):
+                    ctx.batch_upload_async(j, pins[c][j].ctypes.data, W, H, pitch, H * pitch)
         done = [0] * C          # steps collected per context
         sent = [0] * C          # steps enqueued per context
 
         def enqueue(c):
             k = sent[c]
-            ctxs[c].batch_track_async(k % 2 if ingest else first_frame[c] + k)
-            if ingest and k + 1 < n_steps:      # the next frame's upload overlaps this step (ring of 2 entries)
-                ctxs[c].batch_upload_async((k + 1) % 2, pins[c][k + 1].ctypes.data, W, H, pitch, H * pitch)
+            ctxs[c].batch_track_async(k % RING if ingest else first_frame[c] + k)
+            if ingest and k + RING - 1 < n_steps:      # uploads run RING - 1 frames ahead of the step that consumes them
+                ctxs[c].batch_upload_async((k + RING - 1) % RING, pins[c][k + RING - 1].ctypes.data, W, H, pitch, H * pitch)
             sent[c] += 1
 
         for c in range(C):

@@ -24,14 +24,21 @@ inline void check(mvo_ctx* ctx, int rc, bool allow_degenerate = false) {
 inline void detect_and_compute(mvo_ctx* ctx, const cv::Mat& image, std::vector<cv::KeyPoint>& keypoints, cv::Mat& descriptors) {
   CV_Assert(image.type() == CV_8UC1 || image.type() == CV_8UC3);
   static_assert(sizeof(mvo_keypoint) == sizeof(cv::KeyPoint), "cv::KeyPoint layout");
-  const int cap = 16384;
-  keypoints.resize(cap);
-  descriptors.create(cap, 32, CV_8U);
+  // staging buffers live as long as the thread: no 16384-entry allocation per frame (cv::ORB returns at most a little over
+  // nfeatures key-points; MVO_E_CAPACITY would say so if a context were configured for more than this)
+  constexpr int cap = 16384;
+  thread_local std::vector<mvo_keypoint> kp_buf(cap);
+  thread_local std::vector<uchar> desc_buf((size_t)cap * 32);
   int n = 0;
-  check(ctx, mvo_orb_detect_and_compute(ctx, image.data, image.cols, image.rows, (int)image.step, image.channels(),
-                                        reinterpret_cast<mvo_keypoint*>(keypoints.data()), descriptors.data, cap, &n));
+  check(ctx, mvo_orb_detect_and_compute(ctx, image.data, image.cols, image.rows, (int)image.step, image.channels(), kp_buf.data(),
+                                        desc_buf.data(), cap, &n));
   keypoints.resize(n);
-  descriptors = n ? descriptors.rowRange(0, n).clone() : cv::Mat();
+  descriptors.create(n, 32, CV_8U);
+  for (int i = 0; i < n; i++) {
+    const mvo_keypoint& k = kp_buf[i];
+    keypoints[i] = cv::KeyPoint{{k.x, k.y}, k.size, k.angle, k.response, k.octave, k.class_id};
+    for (int b = 0; b < 32; b++) descriptors.ptr<uchar>(i)[b] = desc_buf[(size_t)i * 32 + b];
+  }
 }
 
 // Replaces matcher_.knnMatch + the Lowe loop at reference src/feature_processor.cpp:25-41.
