@@ -239,6 +239,13 @@ int mvo_batch_track(mvo_ctx* ctx, int frame_idx, mvo_step_result* out /* [batch]
 int mvo_batch_set_policy(mvo_ctx* ctx, int policy);
 int mvo_batch_get_state(mvo_ctx* ctx, int* state /* [batch] */, int* tracking_count /* [batch] */);
 
+/* Single-stream forms of the same step (a context with cfg.batch == 1, cfg.ring_frames >= 2): mvo_set_intrinsics is
+ * mvo_batch_set_intrinsics; mvo_tracker_step uploads `img` into the next ring entry and runs Tracker::update on it - the
+ * fused per-frame call of src/mono_vo.cpp:116.  Seed once: mvo_batch_preload_frame(ctx, 0, 0, ...), mvo_batch_seed(ctx, 0, ...),
+ * mvo_batch_set_landmarks(ctx, 0, ...). */
+int mvo_set_intrinsics(mvo_ctx* ctx, const double K[9], const double d[5]);
+int mvo_tracker_step(mvo_ctx* ctx, const uint8_t* img, int w, int h, int stride, int channels, mvo_step_result* out);
+
 /* ---- asynchronous ingest (src/mono_vo.cpp:92-100: the image the callback hands to the tracker) ---------------------------
  * mvo_batch_upload_async copies all `batch` mono8 frames of ring entry `frame_idx` (images `slot_stride` bytes apart, rows
  * `stride` bytes apart) host -> device on a dedicated upload stream and returns at once; the step that uses the entry

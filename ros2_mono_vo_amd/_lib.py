@@ -53,7 +53,7 @@ ABI_SYMBOLS = [
     "mvo_batch_preload_frame", "mvo_batch_seed", "mvo_batch_get_tracks", "mvo_batch_set_landmarks",
     "mvo_batch_set_intrinsics", "mvo_batch_step", "mvo_profile_enable", "mvo_profile_read", "mvo_profile_reset",
     "mvo_batch_track_async", "mvo_batch_track_poll", "mvo_batch_track_wait", "mvo_batch_track", "mvo_batch_set_policy",
-    "mvo_batch_get_state", "mvo_batch_upload_async", "mvo_host_alloc", "mvo_host_free",
+    "mvo_batch_get_state", "mvo_batch_upload_async", "mvo_host_alloc", "mvo_host_free", "mvo_set_intrinsics", "mvo_tracker_step",
 ]
 
 

@@ -181,6 +181,13 @@ class Context:
         self._check(self._L.mvo_batch_track(self._h, int(frame_idx), res))
         return res
 
+    def tracker_step(self, img):
+        """Fused single-stream Tracker::update (a context with batch=1, ring_frames>=2)."""
+        img, w, h, stride, ch = self._img(img)
+        res = (_lib.StepResult * 1)()
+        self._check(self._L.mvo_tracker_step(self._h, ptr(img), w, h, stride, ch, res))
+        return res[0]
+
     def batch_set_policy(self, policy):
         self._check(self._L.mvo_batch_set_policy(self._h, int(policy)))
 

@@ -213,6 +213,7 @@ struct PipeState {
   // asynchronous ingest (track.hip): uploads run on their own stream; ev_up[f] = frame f of the ring has landed,
   // ev_rd[f] = the step that consumed frame f has read it (a later upload into that ring entry waits for it)
   hipStream_t s_up = nullptr;
+  int step_entry = 0;       // ring entry mvo_tracker_step used last (the seed frame is entry 0)
   bool up_shared = false;   // uploads ride on the compute stream (MVO_UPLOAD_STREAM=0)
   std::vector<hipEvent_t> ev_up, ev_rd;
   std::vector<char> up_pending, rd_pending;

@@ -8,6 +8,8 @@
 // All per-stream state (previous pyramid, tracked points, landmarks, key-frame descriptors) stays in HBM.
 #include "mvo_internal.h"
 
+#include <dlfcn.h>
+
 #include <map>
 
 // ---------------------------------------------------------------------------------------------------
@@ -22,6 +24,24 @@ struct Prof {
   std::vector<Pending> open;
 };
 
+// roctx ranges around the enqueue of every stage (tracing), resolved at run time so the library has no hard
+// dependency on the tracer: MVO_ROCTX=1 turns them on; `rocprofv3 --marker-trace` shows them beside the kernel trace.
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    const char* e = getenv("MVO_ROCTX");
+    if (!e || atoi(e) == 0) return;
+    void* h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return;
+    push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+    pop = (int (*)())dlsym(h, "roctxRangePop");
+    if (!push || !pop) push = nullptr, pop = nullptr;
+  }
+};
+static Roctx& roctx() { static Roctx r; return r; }
+
 static hipEvent_t prof_event(Prof* p) {
   if (!p->pool.empty()) { hipEvent_t e = p->pool.back(); p->pool.pop_back(); return e; }
   hipEvent_t e;
@@ -30,6 +50,7 @@ static hipEvent_t prof_event(Prof* p) {
 }
 
 void prof_begin(mvo_ctx* ctx, const char* name, hipStream_t st) {
+  if (roctx().push) roctx().push(name);
   Prof* p = ctx->prof;
   if (!p || !p->on) return;
   Prof::Pending q;
@@ -39,6 +60,7 @@ void prof_begin(mvo_ctx* ctx, const char* name, hipStream_t st) {
 }
 
 void prof_end(mvo_ctx* ctx) {
+  if (roctx().pop) roctx().pop();
   Prof* p = ctx->prof;
   if (!p || !p->on || p->open.empty()) return;
   Prof::Pending q = p->open.back();

@@ -682,6 +682,23 @@ extern "C" int mvo_batch_track(mvo_ctx* ctx, int frame_idx, mvo_step_result* out
   return mvo_batch_track_wait(ctx, out);
 }
 
+// ---- single-stream convenience forms (SURVEY 8(b) export list) ------------------------------------------------------------
+extern "C" int mvo_set_intrinsics(mvo_ctx* ctx, const double K[9], const double d[5]) { return mvo_batch_set_intrinsics(ctx, K, d); }
+
+// Fused Tracker::update for a context of ONE stream (cfg.batch == 1, cfg.ring_frames >= 2): uploads the image (any
+// encoding code of this header; colour must be replicated mono8, see mvo_lk_track) into the ring entry after the one used
+// last and runs mvo_batch_track on it.  Seed once with mvo_batch_preload_frame(ctx, 0, 0, ...) + mvo_batch_seed(ctx, 0, ...)
+// + mvo_batch_set_landmarks (the Initializer's hand-over).
+extern "C" int mvo_tracker_step(mvo_ctx* ctx, const uint8_t* img, int w, int h, int stride, int channels, mvo_step_result* out) {
+  if (!ctx || !ctx->pipe || !img || !out) return MVO_E_ARG;
+  PipeState* p = ctx->pipe;
+  if (ctx->B != 1 || p->ring < 2) { ctx->set_error("mvo_tracker_step: needs cfg.batch == 1 and cfg.ring_frames >= 2"); return MVO_E_ARG; }
+  p->step_entry = (p->step_entry + 1) % p->ring;
+  int rc = mvo_batch_preload_frame(ctx, 0, p->step_entry, img, w, h, stride, channels);
+  if (rc) return rc;
+  return mvo_batch_track(ctx, p->step_entry, out);
+}
+
 // Tracker state of every slot: MVO_TRACK_* (and tracking_count_from_keyframe_).  Blocks until queued work has finished.
 extern "C" int mvo_batch_get_state(mvo_ctx* ctx, int* state, int* tracking_count) {
   if (!ctx || !ctx->pipe) return MVO_E_ARG;

@@ -188,3 +188,28 @@ def test_track_reproduces_the_committed_golden_vectors():
                 assert [int(getattr(out[s], key)) for key in gold["keys"]] == g["ints"], (k, kind)
                 if g["ints"][gold["keys"].index("flags")] & _lib.STEP_POSE:
                     assert np.abs(np.array(out[s].rvec) - g["rvec"]).max() < 1e-6 and np.abs(np.array(out[s].tvec) - g["tvec"]).max() < 1e-6
+
+
+def test_single_stream_tracker_step_matches_the_batch_form():
+    """mvo_tracker_step (batch = 1: upload + Tracker::update fused) gives what slot 0 of a batch run gives."""
+    N = 13
+    K = synth.default_K(TS.W, TS.H)
+    fr, d0 = TS.stream("lateral", N)
+    key = lambda o: (o.n_prev, o.n_tracked, o.n_pnp_inliers, o.score_h, o.score_f, o.n_keypoints, o.n_matches, o.n_triangulated, o.state, o.flags,
+                     o.tracking_count, o.n_tracks, tuple(o.rvec), tuple(o.tvec))
+    outs = []
+    for fused in (False, True):
+        with Context(max_width=TS.W, max_height=TS.H, batch=1, nfeatures=1000, max_points=4096, ring_frames=N if not fused else 2) as ctx:
+            ctx.batch_set_intrinsics(K)
+            ctx.batch_preload_frame(0, 0, fr[0])
+            ctx.batch_seed(0)
+            ctx.batch_set_landmarks(0, TS.depth_landmarks(K, d0)(ctx.batch_get_tracks(0)))
+            run = []
+            for k in range(1, N):
+                if fused:
+                    run.append(key(ctx.tracker_step(fr[k])))
+                else:
+                    ctx.batch_preload_frame(0, k, fr[k])
+                    run.append(key(ctx.batch_track(k)[0]))
+            outs.append(run)
+    assert outs[0] == outs[1] and any(o[9] & _lib.STEP_KEYFRAME for o in outs[0])
