@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmvo_hip.so")
+LIB_PATH = os.environ.get("MVO_LIB") or os.path.join(_HERE, "libmvo_hip.so")   # MVO_LIB: a build variant of the same library (kernel experiments)
 
 MVO_OK, MVO_E_ARG, MVO_E_CAPACITY, MVO_E_HIP, MVO_E_DEGENERATE = 0, 1, 2, 3, 4
 _ERR = {1: "MVO_E_ARG", 2: "MVO_E_CAPACITY", 3: "MVO_E_HIP", 4: "MVO_E_DEGENERATE"}

@@ -4,15 +4,16 @@
 // Kernels
 //   pyrdown_kernel : cv::pyrDown ([1 4 6 4 1]^2, (sum+128)>>8, reflect-101), LDS-tiled, one launch per level
 //                    covering every slot of the batch.
-//   lk_track_kernel: ONE WAVEFRONT PER TRACKED POINT, all pyramid levels inside one launch.  Per level the
-//                    wave stages the 24x24 source neighbourhood of the previous image in LDS, derives the
-//                    22x22 Scharr field there, and keeps its 21x21 fixed-point template (I, Ix, Iy) in
-//                    registers: 63 lanes x 7 horizontally adjacent pixels.  The search window of the next
-//                    image is staged as a 32x32 LDS tile (aligned dword loads; re-fetched only when the window
-//                    leaves it).  The inner loop reads two unaligned 8-byte spans as dwords + v_alignbyte,
-//                    packs pixel pairs with v_perm and evaluates the 14-bit bilinear sum with v_dot2c_i32_i16.
-//                    Normal-equation sums are exact integers: int32 per lane, DPP wave reduction of a 16/16
-//                    split, so results are independent of summation order and bit-identical to the oracle.
+//   lk_track_kernel: FOUR TRACKED POINTS PER WAVEFRONT, one per DPP row of 16 lanes, all pyramid levels inside one
+//                    launch.  Per level a row stages the 24x24 source neighbourhood of the previous image in LDS, derives
+//                    the 22x22 Scharr field there, and keeps its 21x21 fixed-point template (I, Ix, Iy) in registers:
+//                    63 segments of 7 horizontally adjacent pixels, four per lane.  The search window of the next image
+//                    is staged as a 32x32 LDS tile (aligned 16-byte loads; re-fetched only when the window leaves it).
+//                    The inner loop reads two unaligned 8-byte spans as dwords + v_alignbyte, packs pixel pairs with
+//                    v_perm and evaluates the 14-bit bilinear sum with v_dot2_i32_i16.  Normal-equation sums are exact
+//                    integers: int32 per lane, DPP row reduction of a 16/16 split, so results are independent of
+//                    summation order and bit-identical to the oracle.  The per-point scalar work (weights, 2x2 solve,
+//                    convergence tests) is done by a row for its point, so one instruction serves four points.
 #include "mvo_internal.h"
 
 // ---------------------------------------------------------------------------------------------------
@@ -136,17 +137,13 @@ struct LkArgs {
   double min_eig;
   // device-driven launch (frame-batch tracker): the points of all slots form one dense work list,
   // work_slot[w] = slot of item w, pt_base[slot] = first item of the slot, pt_base[nslots] = item count; persistent
-  // wavefronts claim LK_CHUNK items at a time from the eight counters work_ctr[0..8) (one per XCD part of the list, zeroed
-  // before the launch).  Null: one wavefront per
-  // (blockIdx.x * 4 + wave, blockIdx.y) with the host-sized grid.
+  // wavefronts claim four items at a time (one per DPP row) from the eight counters work_ctr[0..8) (one per XCD part of the
+  // list, zeroed before the launch).  Null: points blockIdx.x * 4 .. + 3 of slot blockIdx.y with the host-sized grid.
   const int* work_slot;
   const int* pt_base;
   int* work_ctr;
   int nslots;
 };
-#ifndef LK_CHUNK
-#define LK_CHUNK 4
-#endif
 #ifndef LK_PARTS
 #define LK_PARTS 1   // parts of the work list: 8 = one per XCD (5.6x less HBM traffic, but 9-15 % slower: see DESIGN.md)
 #endif
@@ -161,47 +158,61 @@ struct LkArgs {
 
 typedef short lk_short2 __attribute__((ext_vector_type(2)));
 
-// Wave-wide integer sum with DPP adds (no LDS traffic, ~6 dependent VALU ops) -> value in every lane.
-__device__ __forceinline__ int wave_sum_i32_dpp(int v) {
+// ---- four points per wavefront ------------------------------------------------------------------------------------------
+// A wavefront tracks FOUR points at once, one per DPP row of 16 lanes.  Everything that is a per-point scalar in the
+// algorithm (window origin, bilinear weights, the 2x2 solve, the convergence tests: about half of all instructions when
+// a wavefront tracked one point) is computed by the 16 lanes of the point's row, i.e. one instruction serves four points;
+// the per-pixel work is unchanged: lane l of a row owns the 7-pixel row segments s = l + 16 k (k < 4, s < 63) of the
+// 21x21 window - segment s is row s / 3, columns 7 (s % 3) .. + 6 - and keeps their template in registers.  Sums run
+// over a row with four DPP steps (quad_perm, quad_perm, row_half_mirror, row_mirror) and land in every lane of the row.
+// Rows take their own branches (level skipped, minEig reject, iteration counts): the loops are wave-uniform with per-row
+// predicates, and a row never waits for another except by sharing the instruction stream.
+#define LK_G 4    // points per wavefront
+#define LK_NS 4   // segments per lane
+
+struct LkGroupLds {
+  union {
+    struct {
+      unsigned it[LK_IT * LK_IP / 4];   // previous-image neighbourhood (rows of LK_IP bytes)
+      short2 dt[LK_DT * LK_DT];         // Scharr (dx, dy)
+    } s;                                // set-up of a level
+    unsigned jt[LK_JT * LK_JP / 4];     // iterations: next-image search tile (rows of LK_JP bytes); the template is in registers by then
+  };
+  unsigned pad[20];                     // 720 dwords: the four rows of a wavefront start 16 banks apart
+};
+
+// sum over the 16 lanes of a DPP row, in every lane of the row
+__device__ __forceinline__ int row_sum_i32(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
   v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
   v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);  // row_half_mirror
   v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);  // row_mirror
-  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);  // row_bcast:15 -> rows 1,3
-  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);  // row_bcast:31 -> rows 2,3
-  return __builtin_amdgcn_readlane(v, 63);
+  return v;
 }
 
-// Exact 64-bit wave sum of int32 partials: split into a signed high part and an unsigned 16-bit low part,
-// each of which sums without overflow in 32 bits across 64 lanes.
-__device__ __forceinline__ long long wave_sum_exact(int v) {
-  int lo = v & 0xFFFF, hi = v >> 16;
-  return (long long)wave_sum_i32_dpp(hi) * 65536LL + (long long)wave_sum_i32_dpp(lo);
-}
-
-// The same sum when every lane's partial is known to be small enough that the first PLAIN steps of the butterfly cannot
-// overflow: |v| < 2^28 lets groups of 8 lanes (3 steps) be summed in int32, |v| < 2^27 groups of 16 (4 steps); only
-// the remaining steps run on the hi / lo halves.  Bounds used by the callers: |J - I| <= 8160 and |Ix|, |Iy| <= 4080
-// (u8 image, 14-bit weights, 5 extra fractional bits; Scharr taps sum to 16), 7 pixels per lane.
-// The callers turn the sum into a float: (float)(sum * cn).  hi * 65536 + lo is exact in a double (|sum| < 2^47) and so is
-// the product with cn, and v_cvt_f32_f64 rounds to nearest even exactly like the int64 -> float conversion: same float,
-// five VALU instructions instead of the ~25 SALU instructions of the 64-bit integer path.
+// Exact row sum of int32 partials whose total may overflow 32 bits: the first PLAIN butterfly steps are known not to
+// overflow (bounds at the call sites: |J - I| <= 8160 and |Ix|, |Iy| <= 4080 - u8 image, 14-bit weights, 5 extra fractional
+// bits, Scharr taps sum to 16 - 28 pixels per lane), the rest run on a signed high part and an unsigned 16-bit low part.
+// hi * 65536 + lo is exact in a double (|sum| < 2^47), so is the product with cn the callers form, and v_cvt_f32_f64 rounds
+// to nearest even exactly like the int64 -> float conversion of the reference arithmetic.
 template <int PLAIN>
-__device__ __forceinline__ double wave_sum_exact_bounded(int v) {
-  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
-  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);  // row_half_mirror: groups of 8
-  if (PLAIN >= 4) v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);  // row_mirror: groups of 16
+__device__ __forceinline__ double row_sum_exact_bounded(int v) {
+  if (PLAIN >= 1) v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
+  if (PLAIN >= 2) v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
   int lo = v & 0xFFFF, hi = v >> 16;
-  if (PLAIN < 4) {
-    lo += __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xF, 0xF, true);
-    hi += __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xF, 0xF, true);
+  if (PLAIN < 1) {
+    lo += __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true);
+    hi += __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true);
   }
-  lo += __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xA, 0xF, true);  // row_bcast:15
-  hi += __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xA, 0xF, true);
-  lo += __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xC, 0xF, true);  // row_bcast:31
-  hi += __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xC, 0xF, true);
-  return (double)__builtin_amdgcn_readlane(hi, 63) * 65536.0 + (double)__builtin_amdgcn_readlane(lo, 63);
+  if (PLAIN < 2) {
+    lo += __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true);
+    hi += __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true);
+  }
+  lo += __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, true);
+  hi += __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, true);
+  lo += __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xF, 0xF, true);
+  hi += __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xF, 0xF, true);
+  return (double)hi * 65536.0 + (double)lo;
 }
 
 __device__ __forceinline__ void lk_weights(float a, float b, int& w00, int& w01, int& w10, int& w11) {
@@ -214,23 +225,20 @@ __device__ __forceinline__ void lk_weights(float a, float b, int& w00, int& w01,
 
 __device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
 
-struct LkWaveLds {
-  unsigned it[LK_IT * LK_IP / 4];   // previous-image neighbourhood (rows of LK_IP bytes)
-  short2 dt[LK_DT * LK_DT];         // Scharr (dx, dy)
-  unsigned jt[LK_JT * LK_JP / 4];   // next-image search tile (rows of LK_JP bytes)
-};
-
-// Stage ROWS x TW bytes of the image starting at (x0, y0) into LDS rows of PD dwords.  Fast path: the tile lies inside
-// the image -> NX4 aligned 16-byte loads per row (a lane address on the texture path costs the same for 4 or 16
-// bytes), the tile starts `shift` bytes into each LDS row.  Slow path (image border): per-byte reflect-101.  Returns
-// the byte shift (wave-uniform).
+// Stage ROWS x TW bytes of the image starting at (x0, y0) into LDS rows of PD dwords with the 16 lanes of a row.  Fast
+// path: the tile lies inside the image -> NX4 aligned 16-byte loads per tile row (a lane address on the texture path costs
+// the same for 4 or 16 bytes), the tile starts `shift` bytes into each LDS row.  Border path: one dword of a tile row per
+// item, the image row by reflect-101, the four columns from two aligned dwords when they lie inside the image and per
+// byte by reflect-101 otherwise; the tile then starts at byte 0.  Returns the byte shift (uniform over the row).
 template <int ROWS, int TW, int PD, int NX4>
-__device__ __forceinline__ int lk_load_tile(unsigned* lds, const u8* __restrict__ img, int w, int h, int pitch, int x0, int y0, int lane) {
+__device__ __forceinline__ int lk_load_tile16(unsigned* lds, const u8* __restrict__ img, int w, int h, int pitch, int x0, int y0, int l) {
   const int xa = x0 & ~3;
   const bool inside = x0 >= 0 && y0 >= 0 && x0 + TW <= w && y0 + ROWS <= h && xa + 16 * NX4 <= pitch;
   if (inside) {
     const u8* base = img + (size_t)y0 * pitch + xa;
-    for (int i = lane; i < ROWS * NX4; i += 64) {
+#pragma unroll
+    for (int i0 = 0; i0 < ROWS * NX4; i0 += 16) {
+      const int i = i0 + l;
       const int row = i / NX4, k = i - row * NX4;
       const uint4 v = *(const uint4*)(base + (size_t)row * pitch + 16 * k);
       unsigned* d = lds + row * PD + 4 * k;
@@ -238,19 +246,26 @@ __device__ __forceinline__ int lk_load_tile(unsigned* lds, const u8* __restrict_
     }
     return x0 - xa;
   }
-  u8* lb = (u8*)lds;
-  for (int i = lane; i < ROWS * TW; i += 64) {
-    int row = i / TW, col = i - row * TW;
-    int gx = d_reflect101(x0 + col, w), gy = d_reflect101(y0 + row, h);
-    lb[row * (PD * 4) + col] = img[(size_t)gy * pitch + gx];
+  constexpr int ND = TW / 4;
+  for (int i = l; i < ROWS * ND; i += 16) {
+    const int row = i / ND, dc = i - row * ND;
+    const int gy = d_reflect101(y0 + row, h), gx = x0 + 4 * dc;
+    const u8* rp = img + (size_t)gy * pitch;
+    const int a = gx & ~3;
+    unsigned v;
+    if (gx >= 0 && gx + 3 < w && a + 8 <= pitch) {
+      const unsigned d0 = *(const unsigned*)(rp + a), d1 = *(const unsigned*)(rp + a + 4);
+      v = __builtin_amdgcn_alignbyte(d1, d0, gx & 3);
+    } else {
+      v = 0u;
+#pragma unroll
+      for (int b = 0; b < 4; b++) v |= (unsigned)rp[d_reflect101(gx + b, w)] << (8 * b);
+    }
+    lds[row * PD + dc] = v;
   }
   return 0;
 }
 
-// One lane's 7 pixels of (bilinear J - I) against (Ix, Iy) or |.|: two unaligned 8-byte row spans are read
-// as 3 dwords each and re-aligned with v_alignbyte.  v_perm builds the eight VERTICAL pairs V_k = (row0[k], row1[k])
-// as 16-bit lanes - neighbouring pixels share them - and two v_dot2c_i32_i16 per pixel, V_k . (w00, w10) +
-// V_k+1 . (w01, w11), evaluate the 4-tap fixed-point bilinear sum exactly.  Wa = w00 | w10 << 16, Wb = w01 | w11 << 16.
 // (a.lo * b.lo + a.hi * b.hi) + c on packed signed 16-bit pairs, three-operand form (no accumulator move)
 __device__ __forceinline__ int lk_dot2(unsigned a, unsigned b, int c) {
   int r;
@@ -260,52 +275,44 @@ __device__ __forceinline__ int lk_dot2(unsigned a, unsigned b, int c) {
 // low halves of two registers as one packed pair (lo, hi)
 __device__ __forceinline__ unsigned lk_pack16(int lo, int hi) { return __builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x05040100u); }
 
-// IxP / IyP: the lane's seven derivative values as packed pairs (0,1) (2,3) (4,5) (6,-): with the differences packed the same
-// way one v_dot2_i32_i16 accumulates two pixels of sum(diff * Ix) (|diff| <= 8160, |Ix|, |Iy| <= 4080: all fit 16 bits).
-template <bool ERR>
-__device__ __forceinline__ void lk_accumulate(const unsigned* jt, int byte_off, bool active, unsigned Wa, unsigned Wb, const int* Iv,
-                                              const unsigned* IxP, const unsigned* IyP, int& s1, int& s2) {
-  s1 = 0; s2 = 0;
-  if (!active) return;
+// One segment's 7 values of (bilinear J) - I with 5 fractional bits: two unaligned 8-byte row spans are read as 3 dwords
+// each and re-aligned with v_alignbyte.  v_perm builds the eight VERTICAL pairs V_k = (row0[k], row1[k]) as 16-bit lanes -
+// neighbouring pixels share them - and two v_dot2 per pixel, V_k . (w00, w10) + V_k+1 . (w01, w11), evaluate the 4-tap
+// fixed-point bilinear sum exactly.  Wa = w00 | w10 << 16, Wb = w01 | w11 << 16; Iv[k] = 256 - 512 * I starts the
+// accumulator: ((J + 256) >> 9) - I == (J + 256 - 512 * I) >> 9 exactly.
+__device__ __forceinline__ void lk_seg_diff(const unsigned* jt, int byte_off, unsigned Wa, unsigned Wb, const int* Iv, int* diff) {
   const int sh = byte_off & 3;
   const unsigned* q = jt + (byte_off >> 2);
-  unsigned a0 = q[0], a1 = q[1], a2 = q[2];
-  unsigned b0 = q[LK_JP / 4], b1 = q[LK_JP / 4 + 1], b2 = q[LK_JP / 4 + 2];
-  unsigned r0lo = __builtin_amdgcn_alignbyte(a1, a0, sh), r0hi = __builtin_amdgcn_alignbyte(a2, a1, sh);
-  unsigned r1lo = __builtin_amdgcn_alignbyte(b1, b0, sh), r1hi = __builtin_amdgcn_alignbyte(b2, b1, sh);
-  const lk_short2 wb = __builtin_bit_cast(lk_short2, Wb);
-  lk_short2 V[8];
+  const unsigned a0 = q[0], a1 = q[1], a2 = q[2];
+  const unsigned b0 = q[LK_JP / 4], b1 = q[LK_JP / 4 + 1], b2 = q[LK_JP / 4 + 2];
+  const unsigned r0lo = __builtin_amdgcn_alignbyte(a1, a0, sh), r0hi = __builtin_amdgcn_alignbyte(a2, a1, sh);
+  const unsigned r1lo = __builtin_amdgcn_alignbyte(b1, b0, sh), r1hi = __builtin_amdgcn_alignbyte(b2, b1, sh);
+  unsigned V[8];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const unsigned sel = (unsigned)k | (0x0Cu << 8) | ((unsigned)(4 + k) << 16) | (0x0Cu << 24);   // (src1 byte k, src0 byte k)
-    V[k] = __builtin_bit_cast(lk_short2, __builtin_amdgcn_perm(r1lo, r0lo, sel));
-    V[4 + k] = __builtin_bit_cast(lk_short2, __builtin_amdgcn_perm(r1hi, r0hi, sel));
+    V[k] = __builtin_amdgcn_perm(r1lo, r0lo, sel);
+    V[4 + k] = __builtin_amdgcn_perm(r1hi, r0hi, sel);
   }
-  int diff[7];
 #pragma unroll
-  for (int k = 0; k < 7; k++) {
-    int acc = lk_dot2(__builtin_bit_cast(unsigned, V[k]), Wa, Iv[k]);
-    acc = __builtin_amdgcn_sdot2(V[k + 1], wb, acc, false);
-    diff[k] = acc >> 9;   // Iv[k] = 256 - 512 * I:  ((J + 256) >> 9) - I == (J + 256 - 512 * I) >> 9 exactly
-  }
-  if (ERR) {
-#pragma unroll
-    for (int k = 0; k < 7; k++) s1 += abs(diff[k]);
-  } else {
-    const unsigned d01 = lk_pack16(diff[0], diff[1]), d23 = lk_pack16(diff[2], diff[3]), d45 = lk_pack16(diff[4], diff[5]);
-    const unsigned d6 = (unsigned)diff[6] & 0xFFFFu;
-    s1 = lk_dot2(d01, IxP[0], lk_dot2(d23, IxP[1], lk_dot2(d45, IxP[2], lk_dot2(d6, IxP[3], 0))));
-    s2 = lk_dot2(d01, IyP[0], lk_dot2(d23, IyP[1], lk_dot2(d45, IyP[2], lk_dot2(d6, IyP[3], 0))));
-  }
+  for (int k = 0; k < 7; k++) diff[k] = lk_dot2(V[k + 1], Wb, lk_dot2(V[k], Wa, Iv[k])) >> 9;
 }
 
-__device__ __forceinline__ void lk_track_point(const LkArgs& A, LkWaveLds& S, const int slot, const int p, const int lane) {
-  const size_t pidx = (size_t)slot * A.maxpts + p;
+// `S` is the row's LDS block, `l` the lane within the row, (slot, p) the row's point; a row without a point has valid = false.
+__device__ __forceinline__ void lk_track_group(const LkArgs& A, LkGroupLds& S, const int slot, const int p, const bool valid, const int l) {
+  const size_t pidx = valid ? (size_t)slot * A.maxpts + p : 0;
   const float ptx = A.prev_pts[2 * pidx], pty = A.prev_pts[2 * pidx + 1];
   const float FLT_SCALE = 1.f / (1 << 20);
   const float half = (LK_WIN - 1) * 0.5f;
-  const int r = lane / 3, x0 = (lane - r * 3) * 7;
-  const bool active = lane < 63;
+  const double cnd = (double)A.cn;
+  int sr[LK_NS], sc[LK_NS];   // row and first column of the lane's segments
+#pragma unroll
+  for (int k = 0; k < LK_NS; k++) {
+    const int s = l + 16 * k;
+    sr[k] = __umul24(s, 21846) >> 16;   // s / 3 for s < 2^15
+    sc[k] = (s - 3 * sr[k]) * 7;
+  }
+  const bool last_active = l < 15;   // segment 63 (k = 3, l = 15) does not exist
 
   int status = 1;
   float errv = 0.f;
@@ -315,6 +322,7 @@ __device__ __forceinline__ void lk_track_point(const LkArgs& A, LkWaveLds& S, co
     const LkLevelDesc lv = A.lv[level];
     const u8* I = lv.I + (size_t)slot * A.slot_stride;
     const u8* J = lv.J + (size_t)slot * A.slot_stride;
+    bool go = valid;
     float px = ptx * (float)(1. / (1 << level));
     float py = pty * (float)(1. / (1 << level));
     float nx, ny;
@@ -322,213 +330,246 @@ __device__ __forceinline__ void lk_track_point(const LkArgs& A, LkWaveLds& S, co
     else { nx = sx * 2.f; ny = sy * 2.f; }
     sx = nx; sy = ny;
     px -= half; py -= half;
-    int ipx = d_cv_floor(px), ipy = d_cv_floor(py);
+    const int ipx = d_cv_floor(px), ipy = d_cv_floor(py);
     if (ipx < -LK_WIN || ipx >= lv.w || ipy < -LK_WIN || ipy >= lv.h) {
       if (level == 0) { status = 0; errv = 0.f; }
-      continue;
+      go = false;
     }
     // ---- stage the 24x24 neighbourhood of I (origin ipx-1, ipy-1) -------------------------------------
-    __builtin_amdgcn_wave_barrier();
-    const int shI = lk_load_tile<LK_IT, LK_IT, LK_IP / 4, 2>(S.it, I, lv.w, lv.h, lv.pitch, ipx - 1, ipy - 1, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();   // the search tile of the previous level shares this memory
+    int shI = 0;
+    if (go) shI = lk_load_tile16<LK_IT, LK_IT, LK_IP / 4, 2>(S.s.it, I, lv.w, lv.h, lv.pitch, ipx - 1, ipy - 1, l);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // ---- Scharr field on the 22x22 window-source positions (zero outside the image) --------------
-    // Separable form, 11 pixels per lane (22 rows x 2 halves): with S = 3*(top + bottom) + 10*mid and D = bottom - top
-    // per column, dx = S[c+1] - S[c-1] and dy = 3*(D[c-1] + D[c+1]) + 10*D[c].  Three tile rows of 13 bytes come in as
-    // 4 aligned dwords each and are re-phased with v_alignbyte.
-    if (lane < 2 * LK_DT) {
-      const int ty = lane >> 1, hx = lane & 1, tx0 = 11 * hx;
-      const int bo = shI + tx0, ph = bo & 3;
-      const unsigned* rp = S.it + ty * (LK_IP / 4) + (bo >> 2);
-      unsigned col[3][4];   // bytes tx0 .. tx0+12 of tile rows ty, ty+1, ty+2 (byte 12 in col[.][3] bits 0-7)
+    // Separable form, 11 pixels per item (22 rows x 2 halves = 44 items over the 16 lanes): with S = 3*(top + bottom) +
+    // 10*mid and D = bottom - top per column, dx = S[c+1] - S[c-1] and dy = 3*(D[c-1] + D[c+1]) + 10*D[c].  Three tile
+    // rows of 13 bytes come in as 4 aligned dwords each and are re-phased with v_alignbyte.
+    if (go) {
+#pragma unroll 1
+      for (int k = 0; k < 3; k++) {
+        const int item = l + 16 * k;
+        if (item < 2 * LK_DT) {
+          const int ty = item >> 1, hx = item & 1, tx0 = 11 * hx;
+          const int bo = shI + tx0, ph = bo & 3;
+          const unsigned* rp = S.s.it + ty * (LK_IP / 4) + (bo >> 2);
+          unsigned col[3][4];   // bytes tx0 .. tx0+12 of tile rows ty, ty+1, ty+2 (byte 12 in col[.][3] bits 0-7)
 #pragma unroll
-      for (int q = 0; q < 3; q++) {
-        const unsigned d0 = rp[q * (LK_IP / 4)], d1 = rp[q * (LK_IP / 4) + 1], d2 = rp[q * (LK_IP / 4) + 2], d3 = rp[q * (LK_IP / 4) + 3];
-        col[q][0] = __builtin_amdgcn_alignbyte(d1, d0, ph);
-        col[q][1] = __builtin_amdgcn_alignbyte(d2, d1, ph);
-        col[q][2] = __builtin_amdgcn_alignbyte(d3, d2, ph);
-        col[q][3] = d3 >> (8 * ph);
-      }
-      // packed 16-bit arithmetic, two columns per register: S <= 4080 and |D| <= 255, |dx|, |dy| <= 4080
-      typedef unsigned short lk_us2 __attribute__((ext_vector_type(2)));
-      lk_us2 Sp[7], Dp[7];   // columns (2j, 2j+1); column 13 is padding and only reaches the unused output 11
+          for (int q = 0; q < 3; q++) {
+            const unsigned d0 = rp[q * (LK_IP / 4)], d1 = rp[q * (LK_IP / 4) + 1], d2 = rp[q * (LK_IP / 4) + 2], d3 = rp[q * (LK_IP / 4) + 3];
+            col[q][0] = __builtin_amdgcn_alignbyte(d1, d0, ph);
+            col[q][1] = __builtin_amdgcn_alignbyte(d2, d1, ph);
+            col[q][2] = __builtin_amdgcn_alignbyte(d3, d2, ph);
+            col[q][3] = d3 >> (8 * ph);
+          }
+          // packed 16-bit arithmetic, two columns per register: S <= 4080 and |D| <= 255, |dx|, |dy| <= 4080
+          typedef unsigned short lk_us2 __attribute__((ext_vector_type(2)));
+          lk_us2 Sp[7], Dp[7];   // columns (2j, 2j+1); column 13 is padding and only reaches the unused output 11
 #pragma unroll
-      for (int j = 0; j < 7; j++) {
-        const unsigned selp = (j & 1) ? 0x0c030c02u : 0x0c010c00u;   // bytes (2, 3) / (0, 1) of the dword as two u16
-        const lk_us2 t = __builtin_bit_cast(lk_us2, __builtin_amdgcn_perm(0u, col[0][j >> 1], selp));
-        const lk_us2 m = __builtin_bit_cast(lk_us2, __builtin_amdgcn_perm(0u, col[1][j >> 1], selp));
-        const lk_us2 b = __builtin_bit_cast(lk_us2, __builtin_amdgcn_perm(0u, col[2][j >> 1], selp));
-        const lk_us2 three = {3, 3}, ten = {10, 10};
-        Sp[j] = (t + b) * three + m * ten;
-        Dp[j] = b - t;   // two's complement in 16 bits
-      }
-      const int gy = ipy + ty, gx0 = ipx + tx0;
-      const bool row_ok = (unsigned)gy < (unsigned)lv.h;
-      const bool all_ok = row_ok && gx0 >= 0 && gx0 + 10 < lv.w;
-      const bool fast = __all(all_ok) != 0;   // nearly always: the window lies inside the image
-      unsigned* dst = (unsigned*)&S.dt[ty * LK_DT + tx0];
+          for (int j = 0; j < 7; j++) {
+            const unsigned selp = (j & 1) ? 0x0c030c02u : 0x0c010c00u;   // bytes (2, 3) / (0, 1) of the dword as two u16
+            const lk_us2 t = __builtin_bit_cast(lk_us2, __builtin_amdgcn_perm(0u, col[0][j >> 1], selp));
+            const lk_us2 m = __builtin_bit_cast(lk_us2, __builtin_amdgcn_perm(0u, col[1][j >> 1], selp));
+            const lk_us2 b = __builtin_bit_cast(lk_us2, __builtin_amdgcn_perm(0u, col[2][j >> 1], selp));
+            const lk_us2 three = {3, 3}, ten = {10, 10};
+            Sp[j] = (t + b) * three + m * ten;
+            Dp[j] = b - t;   // two's complement in 16 bits
+          }
+          const int gy = ipy + ty, gx0 = ipx + tx0;
+          const bool row_ok = (unsigned)gy < (unsigned)lv.h;
+          const bool all_ok = row_ok && gx0 >= 0 && gx0 + 10 < lv.w;   // nearly always: the window lies inside the image
+          unsigned* dst = (unsigned*)&S.s.dt[ty * LK_DT + tx0];
 #pragma unroll
-      for (int j = 0; j < 6; j++) {
-        const lk_us2 three = {3, 3}, ten = {10, 10};
-        const lk_us2 dxp = Sp[j + 1] - Sp[j];                                    // dx of outputs 2j, 2j+1
-        const lk_us2 mid = __builtin_bit_cast(lk_us2, __builtin_amdgcn_alignbyte(__builtin_bit_cast(unsigned, Dp[j + 1]),
-                                                                                  __builtin_bit_cast(unsigned, Dp[j]), 2));
-        const lk_us2 dyp = (Dp[j] + Dp[j + 1]) * three + mid * ten;              // dy of outputs 2j, 2j+1
-        const unsigned X = __builtin_bit_cast(unsigned, dxp), Y = __builtin_bit_cast(unsigned, dyp);
-        unsigned e0 = __builtin_amdgcn_perm(Y, X, 0x05040100u);                  // (dx, dy) of output 2j
-        unsigned e1 = __builtin_amdgcn_perm(Y, X, 0x07060302u);                  // (dx, dy) of output 2j+1
-        if (!fast) {
-          if (!(row_ok && (unsigned)(gx0 + 2 * j) < (unsigned)lv.w)) e0 = 0u;
-          if (!(row_ok && (unsigned)(gx0 + 2 * j + 1) < (unsigned)lv.w)) e1 = 0u;
+          for (int j = 0; j < 6; j++) {
+            const lk_us2 three = {3, 3}, ten = {10, 10};
+            const lk_us2 dxp = Sp[j + 1] - Sp[j];                                    // dx of outputs 2j, 2j+1
+            const lk_us2 mid = __builtin_bit_cast(lk_us2, __builtin_amdgcn_alignbyte(__builtin_bit_cast(unsigned, Dp[j + 1]),
+                                                                                      __builtin_bit_cast(unsigned, Dp[j]), 2));
+            const lk_us2 dyp = (Dp[j] + Dp[j + 1]) * three + mid * ten;              // dy of outputs 2j, 2j+1
+            const unsigned X = __builtin_bit_cast(unsigned, dxp), Y = __builtin_bit_cast(unsigned, dyp);
+            unsigned e0 = __builtin_amdgcn_perm(Y, X, 0x05040100u);                  // (dx, dy) of output 2j
+            unsigned e1 = __builtin_amdgcn_perm(Y, X, 0x07060302u);                  // (dx, dy) of output 2j+1
+            if (!all_ok) {
+              if (!(row_ok && (unsigned)(gx0 + 2 * j) < (unsigned)lv.w)) e0 = 0u;
+              if (!(row_ok && (unsigned)(gx0 + 2 * j + 1) < (unsigned)lv.w)) e1 = 0u;
+            }
+            dst[2 * j] = e0;
+            if (j < 5) dst[2 * j + 1] = e1;   // output 11 does not exist
+          }
         }
-        dst[2 * j] = e0;
-        if (j < 5) dst[2 * j + 1] = e1;   // output 11 does not exist
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // ---- template in registers + exact A sums ---------------------------------------------------------
     // Same machinery as the iteration: vertical 16-bit pairs (row r, row r + 1) by v_perm, shared by neighbouring
-    // pixels, and the 4-tap fixed-point sums by two v_dot2c_i32_i16; the derivative field is interleaved (dx, dy), so
-    // the low / high halves of two vertically adjacent entries give the dx / dy pairs.
-    int w00, w01, w10, w11;
-    lk_weights(px - ipx, py - ipy, w00, w01, w10, w11);
-    int Iv[7];
-    unsigned IxP[4], IyP[4];   // (Ix, Iy) of the lane's 7 pixels as packed 16-bit pairs (0,1) (2,3) (4,5) (6,-)
-    int a11 = 0, a12 = 0, a22 = 0;
-    if (active) {
-      const lk_short2 wa = __builtin_bit_cast(lk_short2, (unsigned)w00 | ((unsigned)w10 << 16));
-      const lk_short2 wb = __builtin_bit_cast(lk_short2, (unsigned)w01 | ((unsigned)w11 << 16));
-      {
-        const int bo = (r + 1) * LK_IP + x0 + 1 + shI, sh = bo & 3;
-        const unsigned* q = S.it + (bo >> 2);
-        const unsigned a0 = q[0], a1 = q[1], a2 = q[2];
-        const unsigned b0 = q[LK_IP / 4], b1 = q[LK_IP / 4 + 1], b2 = q[LK_IP / 4 + 2];
-        const unsigned r0lo = __builtin_amdgcn_alignbyte(a1, a0, sh), r0hi = __builtin_amdgcn_alignbyte(a2, a1, sh);
-        const unsigned r1lo = __builtin_amdgcn_alignbyte(b1, b0, sh), r1hi = __builtin_amdgcn_alignbyte(b2, b1, sh);
-        lk_short2 V[8];
+    // pixels, and the 4-tap fixed-point sums by two v_dot2; the derivative field is interleaved (dx, dy), so the low /
+    // high halves of two vertically adjacent entries give the dx / dy pairs.
+    int Iv[LK_NS][7];
+    unsigned IxP[LK_NS][4], IyP[LK_NS][4];   // (Ix, Iy) of a segment's 7 pixels as packed 16-bit pairs (0,1) (2,3) (4,5) (6,-)
+    float A11 = 0.f, A12 = 0.f, A22 = 0.f, D = 1.f;
+    if (go) {
+      int w00, w01, w10, w11;
+      lk_weights(px - ipx, py - ipy, w00, w01, w10, w11);
+      const unsigned Wa = (unsigned)w00 | ((unsigned)w10 << 16), Wb = (unsigned)w01 | ((unsigned)w11 << 16);
+      int a11 = 0, a12 = 0, a22 = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const unsigned sel = (unsigned)k | (0x0Cu << 8) | ((unsigned)(4 + k) << 16) | (0x0Cu << 24);
-          V[k] = __builtin_bit_cast(lk_short2, __builtin_amdgcn_perm(r1lo, r0lo, sel));
-          V[4 + k] = __builtin_bit_cast(lk_short2, __builtin_amdgcn_perm(r1hi, r0hi, sel));
+      for (int k = 0; k < LK_NS; k++) {
+        if (k < LK_NS - 1 || last_active) {
+          {
+            const int bo = (sr[k] + 1) * LK_IP + sc[k] + 1 + shI, sh = bo & 3;
+            const unsigned* q = S.s.it + (bo >> 2);
+            const unsigned a0 = q[0], a1 = q[1], a2 = q[2];
+            const unsigned b0 = q[LK_IP / 4], b1 = q[LK_IP / 4 + 1], b2 = q[LK_IP / 4 + 2];
+            const unsigned r0lo = __builtin_amdgcn_alignbyte(a1, a0, sh), r0hi = __builtin_amdgcn_alignbyte(a2, a1, sh);
+            const unsigned r1lo = __builtin_amdgcn_alignbyte(b1, b0, sh), r1hi = __builtin_amdgcn_alignbyte(b2, b1, sh);
+            unsigned V[8];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              const unsigned sel = (unsigned)i | (0x0Cu << 8) | ((unsigned)(4 + i) << 16) | (0x0Cu << 24);
+              V[i] = __builtin_amdgcn_perm(r1lo, r0lo, sel);
+              V[4 + i] = __builtin_amdgcn_perm(r1hi, r0hi, sel);
+            }
+#pragma unroll
+            for (int i = 0; i < 7; i++)   // kept as the start value of the iteration's accumulator (lk_seg_diff)
+              Iv[k][i] = 256 - (descale(lk_dot2(V[i + 1], Wb, lk_dot2(V[i], Wa, 0)), 14 - 5) << 9);
+          }
+          const unsigned* d0 = (const unsigned*)&S.s.dt[sr[k] * LK_DT + sc[k]];
+          const unsigned* d1 = d0 + LK_DT;
+          unsigned XV[8], YV[8];   // (dx, dx below), (dy, dy below) at positions sc .. sc + 7
+#pragma unroll
+          for (int i = 0; i < 8; i++) {
+            const unsigned e0 = d0[i], e1 = d1[i];
+            XV[i] = __builtin_amdgcn_perm(e1, e0, 0x05040100u);
+            YV[i] = __builtin_amdgcn_perm(e1, e0, 0x07060302u);
+          }
+          int ixv[7], iyv[7];
+#pragma unroll
+          for (int i = 0; i < 7; i++) {
+            ixv[i] = descale(lk_dot2(XV[i + 1], Wb, lk_dot2(XV[i], Wa, 0)), 14);
+            iyv[i] = descale(lk_dot2(YV[i + 1], Wb, lk_dot2(YV[i], Wa, 0)), 14);
+          }
+#pragma unroll
+          for (int j = 0; j < 3; j++) { IxP[k][j] = lk_pack16(ixv[2 * j], ixv[2 * j + 1]); IyP[k][j] = lk_pack16(iyv[2 * j], iyv[2 * j + 1]); }
+          IxP[k][3] = (unsigned)ixv[6] & 0xFFFFu; IyP[k][3] = (unsigned)iyv[6] & 0xFFFFu;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {   // sum(ix * ix) etc. two pixels per instruction; exact integers either way
+            a11 = lk_dot2(IxP[k][j], IxP[k][j], a11); a12 = lk_dot2(IxP[k][j], IyP[k][j], a12); a22 = lk_dot2(IyP[k][j], IyP[k][j], a22);
+          }
         }
-#pragma unroll
-        for (int i = 0; i < 7; i++) {
-          int acc = __builtin_amdgcn_sdot2(V[i], wa, 0, false);
-          acc = __builtin_amdgcn_sdot2(V[i + 1], wb, acc, false);
-          Iv[i] = 256 - (descale(acc, 14 - 5) << 9);   // kept as the start value of the iteration's accumulator (lk_accumulate)
-        }
       }
-      const unsigned* d0 = (const unsigned*)&S.dt[r * LK_DT + x0];
-      const unsigned* d1 = d0 + LK_DT;
-      lk_short2 XV[8], YV[8];   // (dx, dx below), (dy, dy below) at positions x0 .. x0 + 7
-#pragma unroll
-      for (int i = 0; i < 8; i++) {
-        const unsigned e0 = d0[i], e1 = d1[i];
-        XV[i] = __builtin_bit_cast(lk_short2, __builtin_amdgcn_perm(e1, e0, 0x05040100u));
-        YV[i] = __builtin_bit_cast(lk_short2, __builtin_amdgcn_perm(e1, e0, 0x07060302u));
+      // per lane: 28 * 4080^2 < 2^29 -> two plain butterfly steps
+      const double sA11 = row_sum_exact_bounded<2>(a11), sA12 = row_sum_exact_bounded<2>(a12), sA22 = row_sum_exact_bounded<2>(a22);
+      A11 = (float)(sA11 * cnd) * FLT_SCALE;
+      A12 = (float)(sA12 * cnd) * FLT_SCALE;
+      A22 = (float)(sA22 * cnd) * FLT_SCALE;
+      D = A11 * A22 - A12 * A12;
+      const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * LK_WIN * LK_WIN);
+      if ((double)minEig < A.min_eig || D < 1.1920928955078125e-07f) {
+        if (level == 0) status = 0;
+        go = false;
       }
-      int ixv[7], iyv[7];
-#pragma unroll
-      for (int i = 0; i < 7; i++) {
-        int ix = __builtin_amdgcn_sdot2(XV[i], wa, 0, false);
-        ixv[i] = descale(__builtin_amdgcn_sdot2(XV[i + 1], wb, ix, false), 14);
-        int iy = __builtin_amdgcn_sdot2(YV[i], wa, 0, false);
-        iyv[i] = descale(__builtin_amdgcn_sdot2(YV[i + 1], wb, iy, false), 14);
-      }
-#pragma unroll
-      for (int j = 0; j < 3; j++) { IxP[j] = lk_pack16(ixv[2 * j], ixv[2 * j + 1]); IyP[j] = lk_pack16(iyv[2 * j], iyv[2 * j + 1]); }
-      IxP[3] = (unsigned)ixv[6] & 0xFFFFu; IyP[3] = (unsigned)iyv[6] & 0xFFFFu;
-#pragma unroll
-      for (int j = 0; j < 4; j++) {   // sum(ix * ix) etc. two pixels per instruction; exact integers either way
-        a11 = lk_dot2(IxP[j], IxP[j], a11); a12 = lk_dot2(IxP[j], IyP[j], a12); a22 = lk_dot2(IyP[j], IyP[j], a22);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 7; i++) Iv[i] = 256;
-#pragma unroll
-      for (int j = 0; j < 4; j++) { IxP[j] = 0u; IyP[j] = 0u; }
     }
-    // per lane: 7 * 4080^2 < 2^27
-    const double cnd = (double)A.cn;
-    const double sA11 = wave_sum_exact_bounded<4>(a11), sA12 = wave_sum_exact_bounded<4>(a12), sA22 = wave_sum_exact_bounded<4>(a22);
-    float A11 = (float)(sA11 * cnd) * FLT_SCALE;
-    float A12 = (float)(sA12 * cnd) * FLT_SCALE;
-    float A22 = (float)(sA22 * cnd) * FLT_SCALE;
-    float D = A11 * A22 - A12 * A12;
-    float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) /
-                   (float)(2 * LK_WIN * LK_WIN);
-    if ((double)minEig < A.min_eig || D < 1.1920928955078125e-07f) {
-      if (level == 0) status = 0;
-      continue;
-    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();   // the search tile overwrites the set-up tiles from here on
     D = 1.f / D;
     nx -= half; ny -= half;
     float pdx = 0.f, pdy = 0.f;
     int jx0 = 0, jy0 = 0, shJ = 0;
     bool have_tile = false;
+    bool iter = go;
     for (int j = 0; j < A.max_count; j++) {
-      int inx = d_cv_floor(nx), iny = d_cv_floor(ny);
-      if (inx < -LK_WIN || inx >= lv.w || iny < -LK_WIN || iny >= lv.h) {
-        if (level == 0) status = 0;
-        break;
+      if (!__any(iter)) break;
+      if (iter) {
+        const int inx = d_cv_floor(nx), iny = d_cv_floor(ny);
+        if (inx < -LK_WIN || inx >= lv.w || iny < -LK_WIN || iny >= lv.h) {
+          if (level == 0) status = 0;
+          iter = false;
+        } else {
+          int ddx = inx - jx0, ddy = iny - jy0;
+          if (!have_tile || ddx < 0 || ddx > LK_JT - (LK_WIN + 1) || ddy < 0 || ddy > LK_JT - (LK_WIN + 1)) {
+            jx0 = inx - LK_JSLACK; jy0 = iny - LK_JSLACK;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            shJ = lk_load_tile16<LK_JT, LK_JT, LK_JP / 4, 3>(S.jt, J, lv.w, lv.h, lv.pitch, jx0, jy0, l);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            have_tile = true;
+            ddx = LK_JSLACK; ddy = LK_JSLACK;
+          }
+          int w00, w01, w10, w11;
+          lk_weights(nx - inx, ny - iny, w00, w01, w10, w11);
+          const unsigned Wa = (unsigned)w00 | ((unsigned)w10 << 16), Wb = (unsigned)w01 | ((unsigned)w11 << 16);
+          const int jbase = ddy * LK_JP + ddx + shJ;
+          int s1 = 0, s2 = 0;
+#pragma unroll
+          for (int k = 0; k < LK_NS; k++) {
+            if (k < LK_NS - 1 || last_active) {
+              int diff[7];
+              lk_seg_diff(S.jt, sr[k] * LK_JP + sc[k] + jbase, Wa, Wb, Iv[k], diff);
+              // differences packed like the derivatives: one v_dot2 accumulates two pixels of sum(diff * Ix)
+              const unsigned d01 = lk_pack16(diff[0], diff[1]), d23 = lk_pack16(diff[2], diff[3]), d45 = lk_pack16(diff[4], diff[5]);
+              const unsigned d6 = (unsigned)diff[6] & 0xFFFFu;
+              s1 = lk_dot2(d01, IxP[k][0], lk_dot2(d23, IxP[k][1], lk_dot2(d45, IxP[k][2], lk_dot2(d6, IxP[k][3], s1))));
+              s2 = lk_dot2(d01, IyP[k][0], lk_dot2(d23, IyP[k][1], lk_dot2(d45, IyP[k][2], lk_dot2(d6, IyP[k][3], s2))));
+            }
+          }
+          // per lane: 28 * 8160 * 4080 < 2^30 -> one plain butterfly step
+          const double sb1 = row_sum_exact_bounded<1>(s1), sb2 = row_sum_exact_bounded<1>(s2);
+          const float b1 = (float)(sb1 * cnd) * FLT_SCALE;
+          const float b2 = (float)(sb2 * cnd) * FLT_SCALE;
+          const float dx = (A12 * b2 - A22 * b1) * D;
+          const float dy = (A12 * b1 - A11 * b2) * D;
+          nx += dx; ny += dy;
+          sx = nx + half; sy = ny + half;
+          if ((double)dx * dx + (double)dy * dy <= A.eps2) iter = false;
+          else if (j > 0 && (double)fabsf(dx + pdx) < 0.01 && (double)fabsf(dy + pdy) < 0.01) {
+            sx -= dx * 0.5f;
+            sy -= dy * 0.5f;
+            iter = false;
+          }
+          pdx = dx; pdy = dy;
+        }
       }
-      int ddx = inx - jx0, ddy = iny - jy0;
-      if (!have_tile || ddx < 0 || ddx > LK_JT - (LK_WIN + 1) || ddy < 0 || ddy > LK_JT - (LK_WIN + 1)) {
-        jx0 = inx - LK_JSLACK; jy0 = iny - LK_JSLACK;
-        __builtin_amdgcn_wave_barrier();
-        shJ = lk_load_tile<LK_JT, LK_JT, LK_JP / 4, 3>(S.jt, J, lv.w, lv.h, lv.pitch, jx0, jy0, lane);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        have_tile = true;
-        ddx = LK_JSLACK; ddy = LK_JSLACK;
-      }
-      lk_weights(nx - inx, ny - iny, w00, w01, w10, w11);
-      int s1, s2;
-      lk_accumulate<false>(S.jt, (r + ddy) * LK_JP + x0 + ddx + shJ, active, (unsigned)w00 | ((unsigned)w10 << 16),
-                           (unsigned)w01 | ((unsigned)w11 << 16), Iv, IxP, IyP, s1, s2);
-      const double sb1 = wave_sum_exact_bounded<3>(s1), sb2 = wave_sum_exact_bounded<3>(s2);  // per lane: 7 * 8160 * 4080 < 2^28
-      float b1 = (float)(sb1 * cnd) * FLT_SCALE;
-      float b2 = (float)(sb2 * cnd) * FLT_SCALE;
-      float dx = (A12 * b2 - A22 * b1) * D;
-      float dy = (A12 * b1 - A11 * b2) * D;
-      nx += dx; ny += dy;
-      sx = nx + half; sy = ny + half;
-      if ((double)dx * dx + (double)dy * dy <= A.eps2) break;
-      if (j > 0 && (double)fabsf(dx + pdx) < 0.01 && (double)fabsf(dy + pdy) < 0.01) {
-        sx -= dx * 0.5f;
-        sy -= dy * 0.5f;
-        break;
-      }
-      pdx = dx; pdy = dy;
     }
-    if (status && level == 0) {
-      float ex = sx - half, ey = sy - half;
-      int inx = d_cv_floor(ex), iny = d_cv_floor(ey);
+    if (go && status && level == 0) {
+      const float ex = sx - half, ey = sy - half;
+      const int inx = d_cv_floor(ex), iny = d_cv_floor(ey);
       if (inx < -LK_WIN || inx >= lv.w || iny < -LK_WIN || iny >= lv.h) {
         status = 0;
       } else {
         int ddx = inx - jx0, ddy = iny - jy0;
         if (!have_tile || ddx < 0 || ddx > LK_JT - (LK_WIN + 1) || ddy < 0 || ddy > LK_JT - (LK_WIN + 1)) {
           jx0 = inx - LK_JSLACK; jy0 = iny - LK_JSLACK;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
-          shJ = lk_load_tile<LK_JT, LK_JT, LK_JP / 4, 3>(S.jt, J, lv.w, lv.h, lv.pitch, jx0, jy0, lane);
+          shJ = lk_load_tile16<LK_JT, LK_JT, LK_JP / 4, 3>(S.jt, J, lv.w, lv.h, lv.pitch, jx0, jy0, l);
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           ddx = LK_JSLACK; ddy = LK_JSLACK;
         }
+        int w00, w01, w10, w11;
         lk_weights(ex - inx, ey - iny, w00, w01, w10, w11);
-        int s1, s2;
-        lk_accumulate<true>(S.jt, (r + ddy) * LK_JP + x0 + ddx + shJ, active, (unsigned)w00 | ((unsigned)w10 << 16),
-                            (unsigned)w01 | ((unsigned)w11 << 16), Iv, IxP, IyP, s1, s2);
-        const double se = (double)wave_sum_i32_dpp(s1);  // 64 * 7 * 8160 fits 32 bits
-        float errval = (float)(se * cnd);
+        const unsigned Wa = (unsigned)w00 | ((unsigned)w10 << 16), Wb = (unsigned)w01 | ((unsigned)w11 << 16);
+        const int jbase = ddy * LK_JP + ddx + shJ;
+        int s1 = 0;
+#pragma unroll
+        for (int k = 0; k < LK_NS; k++) {
+          if (k < LK_NS - 1 || last_active) {
+            int diff[7];
+            lk_seg_diff(S.jt, sr[k] * LK_JP + sc[k] + jbase, Wa, Wb, Iv[k], diff);
+#pragma unroll
+            for (int i = 0; i < 7; i++) s1 += abs(diff[i]);
+          }
+        }
+        const double se = (double)row_sum_i32(s1);  // 16 * 28 * 8160 fits 32 bits
+        const float errval = (float)(se * cnd);
         errv = errval * 1.f / (float)(32 * LK_WIN * A.cn * LK_WIN);
       }
     }
   }
-  if (lane == 0) {
+  if (valid && l == 0) {
     A.next_pts[2 * pidx] = sx;
     A.next_pts[2 * pidx + 1] = sy;
     A.status[pidx] = (u8)status;
@@ -536,20 +577,25 @@ __device__ __forceinline__ void lk_track_point(const LkArgs& A, LkWaveLds& S, co
   }
 }
 
-// Register budget: 6 wavefronts per SIMD (<= 80 VGPRs, no spills).  The kernel is a chain of dependent instructions per
-// wavefront (one tracked point), so resident wavefronts are what hides its latencies.
+// One wavefront per workgroup, 11.25 KB of LDS.  Registers: four templates of 15 registers per lane plus the per-point
+// scalars and a segment's working set need ~170 VGPRs -> 3 wavefronts per SIMD (12 points in flight per SIMD).  Measured
+// (1 x 256 streams, 508 k points): 3 per SIMD 3.20 ms, 2 per SIMD (205 VGPRs) 3.53 ms, 4 per SIMD (128 VGPRs, spills) 4.64 ms;
+// one point per wavefront at 6 per SIMD was 3.90 ms.
 #ifndef LK_WAVES_PER_EU
-#define LK_WAVES_PER_EU 6
+#define LK_WAVES_PER_EU 3
 #endif
-__global__ __launch_bounds__(256, LK_WAVES_PER_EU) void lk_track_kernel(LkArgs A) {
-  __shared__ LkWaveLds lds[4];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  LkWaveLds& S = lds[wave];
+#ifndef LK_RESIDENT_PER_CU
+#define LK_RESIDENT_PER_CU (4 * LK_WAVES_PER_EU)
+#endif
+__global__ __launch_bounds__(64, LK_WAVES_PER_EU) void lk_track_kernel(LkArgs A) {
+  __shared__ LkGroupLds lds[LK_G];
+  const int lane = threadIdx.x, g = lane >> 4, l = lane & 15;
+  LkGroupLds& S = lds[g];
   if (A.work_slot) {
-    // The list is slot major.  It is cut into 8 contiguous parts, one per XCD (workgroups go to the XCDs round-robin by
-    // linear id, so blockIdx.x & 7 is the XCD - a speed hint only): an XCD then walks whole slots and both pyramids of a
-    // slot (2.4 MB at 720p) stay in ITS 4 MB L2, instead of every XCD fetching every slot's lines (measured: 4.1x the
-    // algorithmic bytes without the cut).  A wavefront whose part has run dry helps with the next ones.
+    // The list is slot major.  With LK_PARTS = 8 it is cut into contiguous parts, one per XCD (workgroups go to the XCDs
+    // round-robin by linear id, so blockIdx.x & 7 is the XCD - a speed hint only): an XCD then walks whole slots and both
+    // pyramids of a slot (2.4 MB at 720p) stay in ITS 4 MB L2, instead of every XCD fetching every slot's lines.  A
+    // wavefront whose part has run dry helps with the next ones.
     const int total = min(max(A.pt_base[A.nslots], 0), A.nslots * A.maxpts);
     const int home = blockIdx.x % LK_PARTS;
     for (int k = 0; k < LK_PARTS; k++) {   // every wavefront leaves once all counters have passed their parts
@@ -557,23 +603,24 @@ __global__ __launch_bounds__(256, LK_WAVES_PER_EU) void lk_track_kernel(LkArgs A
       const int lo = (int)((long long)total * part / LK_PARTS), hi = (int)((long long)total * (part + 1) / LK_PARTS);
       for (;;) {
         int w0 = 0;
-        if (lane == 0) w0 = atomicAdd(A.work_ctr + part, LK_CHUNK);
+        if (lane == 0) w0 = atomicAdd(A.work_ctr + part, LK_G);
         w0 = lo + __builtin_amdgcn_readfirstlane(w0);
         if (w0 >= hi) break;
-        const int w1 = min(w0 + LK_CHUNK, hi);
-        for (int w = w0; w < w1; w++) {
-          const int slot = min(max(A.work_slot[w], 0), A.nslots - 1);
-          const int p = w - A.pt_base[slot];
-          if (p >= 0 && p < A.maxpts) lk_track_point(A, S, slot, p, lane);   // always true for a consistent list
-        }
+        const int w = w0 + g;
+        bool valid = w < hi;
+        const int slot = valid ? min(max(A.work_slot[w], 0), A.nslots - 1) : 0;
+        const int p = w - A.pt_base[slot];
+        valid = valid && p >= 0 && p < A.maxpts;   // always true for a consistent list
+        lk_track_group(A, S, slot, p, valid, l);
       }
     }
     return;
   }
   const int slot = blockIdx.y;
-  const int p = blockIdx.x * 4 + wave;
-  if (p >= min(A.npts[slot], A.maxpts)) return;  // wave-uniform
-  lk_track_point(A, S, slot, p, lane);
+  const int p = blockIdx.x * LK_G + g;
+  const bool valid = p < min(A.npts[slot], A.maxpts);
+  if (!__any(valid)) return;
+  lk_track_group(A, S, slot, p, valid, l);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -618,15 +665,15 @@ int lk_track_device(mvo_ctx* ctx, int prev_set, int cur_set, const LkLevels& L, 
   A.eps2 = eps * eps;
   A.min_eig = ctx->cfg.lk_min_eig;
   if (d_work_slot) {
-    // persistent wavefronts: LK_WAVES_PER_EU workgroups of 4 per CU is what the kernel's registers allow (256 CUs)
-    const unsigned want = ((unsigned)nslots * (unsigned)ctx->maxpts + 4 * LK_CHUNK - 1) / (4 * LK_CHUNK);
-    const unsigned full = 256u * LK_WAVES_PER_EU;
-    hipLaunchKernelGGL(lk_track_kernel, dim3(want < full ? want : full), dim3(256), 0, st, A);
+    // persistent single-wavefront workgroups, as many as stay resident (256 CUs x 4 SIMDs x LK_WAVES_PER_EU)
+    const unsigned want = ((unsigned)nslots * (unsigned)ctx->maxpts + LK_G - 1) / LK_G;
+    const unsigned full = 256u * LK_RESIDENT_PER_CU;
+    hipLaunchKernelGGL(lk_track_kernel, dim3(want < full ? want : full), dim3(64), 0, st, A);
     return MVO_OK;
   }
   if (max_n <= 0) return MVO_OK;
-  dim3 grid((max_n + 3) / 4, nslots);
-  hipLaunchKernelGGL(lk_track_kernel, grid, dim3(256), 0, st, A);
+  dim3 grid((max_n + LK_G - 1) / LK_G, nslots);
+  hipLaunchKernelGGL(lk_track_kernel, grid, dim3(64), 0, st, A);
   return MVO_OK;
 }
 
