@@ -48,12 +48,12 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--contexts", type=int, default=3, help="contexts per GPU, stepped asynchronously")
+    ap.add_argument("--contexts", type=int, default=4, help="contexts per GPU, stepped asynchronously")
     ap.add_argument("--batch", type=int, default=256, help="independent camera streams per context")
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--nfeatures", type=int, default=2000)
-    ap.add_argument("--ingest-steps", type=int, default=12, help="steps of the value_with_ingest phase (0 = skip)")
+    ap.add_argument("--ingest-steps", type=int, default=16, help="steps of the value_with_ingest phase (0 = skip)")
     ap.add_argument("--ingest-ring", type=int, default=2, help="ring entries the ingest phase cycles through (uploads run ring - 1 frames ahead)")
     ap.add_argument("--extra-steps", type=int, default=5, help="steps of the always-on and key-frame-every-frame phases (0 = skip)")
     ap.add_argument("--cpu-streams", type=int, default=None, help="streams checked against / timed on the CPU oracle (default: host cores)")

@@ -147,7 +147,9 @@ int mvo_find_fundamental_ransac(mvo_ctx* ctx, const float* p1, const float* p2, 
  * cv::solvePnPRansac(obj, img, K, d, rvec, tvec, false, iters, reproj, conf, inliers).
  * d: NULL / zeros, or the 5 plumb-bob coefficients (k1, k2, p1, p2, k3) of sensor_msgs/CameraInfo::d as the reference
  * forwards them: undistortPoints (5 iterations) in the EPnP kernel and the DLT / planar init, distorted projectPoints in
- * the RANSAC error and the Levenberg-Marquardt refine.  n == 4 (P3P) is not built: MVO_E_ARG. */
+ * the RANSAC error and the Levenberg-Marquardt refine.  n == 4 takes OpenCV's model_points == npoints path: solvePnP(SOLVEPNP_P3P)
+ * on the four correspondences (p3p.cpp: Gao's P3P, the fourth point picks the solution), all four inliers, no refinement;
+ * n == 5 likewise returns the EPnP solution as is.  n < 4: MVO_E_ARG (OpenCV asserts). */
 int mvo_solve_pnp_ransac(mvo_ctx* ctx, const float* obj, const float* img, int n, const double K[9],
                          const double d[5], int iters, float reproj_err, double confidence, double rvec[3],
                          double tvec[3], int* inlier_idx, int* n_inliers);
@@ -245,6 +247,31 @@ int mvo_batch_get_state(mvo_ctx* ctx, int* state /* [batch] */, int* tracking_co
  * mvo_batch_set_landmarks(ctx, 0, ...). */
 int mvo_set_intrinsics(mvo_ctx* ctx, const double K[9], const double d[5]);
 int mvo_tracker_step(mvo_ctx* ctx, const uint8_t* img, int w, int h, int stride, int channels, mvo_step_result* out);
+
+/* ---- output side on the device (src/mono_vo.cpp:117-152, src/utils.cpp:85-243) ---------------------------------------------
+ * What MonoVO::image_callback derives from Tracker::update's result before anything reaches a ROS topic, kept per slot on
+ * the device and updated at the end of every mvo_batch_track step once enabled:
+ *   last_pose_ / tracking_valid_ (mono_vo.cpp:119-131) as the REP-103 pose of affine3d_to_odometry_msg /
+ *     affine3d_to_transform_stamped_msg (utils.cpp:85-188): pose_wc = (R_cw, t_cw)^-1 conjugated with
+ *     M = [0 0 1; -1 0 0; 0 -1 0], orientation by tf2::Matrix3x3::getRotation + normalize (x, y, z, w);
+ *   the path (mono_vo.cpp:134-148): one pose appended per frame while tracking is valid;
+ *   the Map as sensor_msgs/PointCloud2 payload (points3d_to_pointcloud_msg, utils.cpp:190-243): every landmark in id
+ *     order - the seed landmarks of mvo_batch_set_landmarks, then what each add_new_keyframe creates (tracker.cpp:218-223) -
+ *     as (z, -x, -y) float32, point_step 12.  width = *n, row_step = 12 * *n, data = the buffer.
+ * mvo_batch_enable_output allocates `map_capacity` landmarks and `path_capacity` poses per slot (MVO_E_CAPACITY from
+ * mvo_batch_track_wait when a slot would exceed them; the excess is dropped); call it before mvo_batch_set_landmarks.
+ * The header stamps / frame ids and the fixed covariances (utils.cpp:131-146) stay with the caller's message objects.
+ * A slot in MVO_TRACK_ABORTED is frozen (the reference process would have died). */
+typedef struct mvo_ros_pose {
+  double position[3];     /* REP-103: x forward, y left, z up */
+  double orientation[4];  /* x, y, z, w */
+  int tracking_valid;     /* tracking_valid_ */
+  int has_pose;           /* last_pose_.has_value() */
+} mvo_ros_pose;
+int mvo_batch_enable_output(mvo_ctx* ctx, int map_capacity, int path_capacity);
+int mvo_batch_get_odometry(mvo_ctx* ctx, mvo_ros_pose* out /* [batch] */);
+int mvo_batch_get_path(mvo_ctx* ctx, int slot, double* poses /* cap x 7: position xyz, orientation xyzw */, int cap, int* n);
+int mvo_batch_get_pointcloud(mvo_ctx* ctx, int slot, float* data /* cap x 3 */, int cap, int* n);
 
 /* ---- asynchronous ingest (src/mono_vo.cpp:92-100: the image the callback hands to the tracker) ---------------------------
  * mvo_batch_upload_async copies all `batch` mono8 frames of ring entry `frame_idx` (images `slot_stride` bytes apart, rows

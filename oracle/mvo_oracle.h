@@ -45,6 +45,8 @@ int orc_recover_pose(const double* E, const float* p1, const float* p2, int n, c
 int orc_rodrigues_v2m(const double* r, double* R);
 int orc_rodrigues_m2v(const double* R, double* r);
 int orc_epnp(const float* obj, const float* img, int n, const double* K, double* rvec, double* tvec);
+int orc_solve_p3p4(const float* obj, const float* img, const double* K, const double* d, double* rvec, double* tvec);
+int orc_solve_deg4(double a, double b, double c, double d, double e, double* roots);
 int orc_solve_pnp_ransac(const float* obj, const float* img, int n, const double* K, const double* d, int iters,
                          float reproj_err, double confidence, double* rvec, double* tvec, int* inlier_idx,
                          int* n_inliers, int* stats);

@@ -623,6 +623,7 @@ static int solve_pnp_iterative(const std::vector<double>& M, const std::vector<d
 }  // namespace orc
 
 #include "orc_pnp_iterative.inc"
+#include "orc_p3p.inc"
 
 using namespace orc;
 
@@ -635,13 +636,29 @@ extern "C" int orc_epnp(const float* obj, const float* img, int n, const double*
   return 0;
 }
 
+// solvePnP(SOLVEPNP_P3P) on four correspondences; returns the number of P3P solutions, the best one in rvec / tvec
+extern "C" int orc_solve_p3p4(const float* obj, const float* img, const double* K, const double* d, double* rvec, double* tvec) {
+  Cam cam = make_cam(K, d);
+  return solve_pnp_p3p4(obj, img, cam, rvec, tvec);
+}
+
+// real roots of a x^4 + b x^3 + c x^2 + d x + e (polynom_solver.cpp solve_deg4); returns their number
+extern "C" int orc_solve_deg4(double a, double b, double c, double d, double e, double* roots) {
+  return p3_solve_deg4(a, b, c, d, e, roots[0], roots[1], roots[2], roots[3]);
+}
+
 extern "C" int orc_solve_pnp_ransac(const float* obj, const float* img, int n, const double* K, const double* d, int iters,
                                     float reproj_err, double confidence, double* rvec, double* tvec, int* inlier_idx,
                                     int* n_inliers, int* stats) {
   if (n < 4) return -1;
   *n_inliers = 0;
   Cam cam = make_cam(K, d);
-  if (n == 4) return -2;  // P3P branch not restated (the tracker declares LOST below 10 points)
+  if (n == 4) {  // model_points == npoints == 4: solvePnP(SOLVEPNP_P3P) on all four, no RANSAC, no refinement
+    if (solve_pnp_p3p4(obj, img, cam, rvec, tvec) == 0) return 0;
+    for (int i = 0; i < n; i++) inlier_idx[i] = i;
+    *n_inliers = n;
+    return 1;
+  }
   PnPCb cb;
   cb.cam = cam;
   if (n == 5) {

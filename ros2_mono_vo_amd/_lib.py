@@ -54,6 +54,7 @@ ABI_SYMBOLS = [
     "mvo_batch_set_intrinsics", "mvo_batch_step", "mvo_profile_enable", "mvo_profile_read", "mvo_profile_reset",
     "mvo_batch_track_async", "mvo_batch_track_poll", "mvo_batch_track_wait", "mvo_batch_track", "mvo_batch_set_policy",
     "mvo_batch_get_state", "mvo_batch_upload_async", "mvo_host_alloc", "mvo_host_free", "mvo_set_intrinsics", "mvo_tracker_step",
+    "mvo_batch_enable_output", "mvo_batch_get_odometry", "mvo_batch_get_path", "mvo_batch_get_pointcloud",
 ]
 
 
@@ -63,6 +64,11 @@ class StepResult(C.Structure):
                 ("rvec", C.c_double * 3), ("tvec", C.c_double * 3), ("score_h", C.c_int), ("score_f", C.c_int),
                 ("n_keypoints", C.c_int), ("n_matches", C.c_int), ("n_triangulated", C.c_int),
                 ("state", C.c_int), ("flags", C.c_uint), ("tracking_count", C.c_int), ("n_tracks", C.c_int)]
+
+
+class RosPose(C.Structure):
+    """Mirror of `mvo_ros_pose` (include/mvo.h)."""
+    _fields_ = [("position", C.c_double * 3), ("orientation", C.c_double * 4), ("tracking_valid", C.c_int), ("has_pose", C.c_int)]
 
 
 STAGE_LK, STAGE_PNP, STAGE_HF, STAGE_ORB, STAGE_MATCH, STAGE_TRIANG, STAGE_ALL = 1, 2, 4, 8, 16, 32, 63

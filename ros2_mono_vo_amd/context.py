@@ -188,6 +188,33 @@ class Context:
         self._check(self._L.mvo_tracker_step(self._h, ptr(img), w, h, stride, ch, res))
         return res[0]
 
+    # -- output side on the device (host restatement of the same arithmetic: ros_io.py) ----------------
+    def batch_enable_output(self, map_capacity=65536, path_capacity=4096):
+        self._check(self._L.mvo_batch_enable_output(self._h, int(map_capacity), int(path_capacity)))
+        self._out_caps = (int(map_capacity), int(path_capacity))
+
+    def batch_get_odometry(self):
+        """-> [batch] _lib.RosPose: last_pose_ in REP-103 (position, orientation xyzw), tracking_valid, has_pose."""
+        out = (_lib.RosPose * int(self.cfg.batch))()
+        self._check(self._L.mvo_batch_get_odometry(self._h, out))
+        return out
+
+    def batch_get_path(self, slot):
+        """-> (n, 7) float64: the slot's nav_msgs/Path poses (position xyz, orientation xyzw)."""
+        cap = self._out_caps[1]
+        buf = np.zeros((cap, 7))
+        n = C.c_int(0)
+        self._check(self._L.mvo_batch_get_path(self._h, int(slot), ptr(buf), cap, C.byref(n)))
+        return buf[:n.value].copy()
+
+    def batch_get_pointcloud(self, slot):
+        """-> (n, 3) float32: the slot's Map as PointCloud2 payload (point_step 12, ROS axes)."""
+        cap = self._out_caps[0]
+        buf = np.zeros((cap, 3), np.float32)
+        n = C.c_int(0)
+        self._check(self._L.mvo_batch_get_pointcloud(self._h, int(slot), ptr(buf), cap, C.byref(n)))
+        return buf[:n.value].copy()
+
     def batch_set_policy(self, policy):
         self._check(self._L.mvo_batch_set_policy(self._h, int(policy)))
 

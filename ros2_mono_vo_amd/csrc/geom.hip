@@ -94,6 +94,25 @@ __global__ __launch_bounds__(64 * NW, RS_WAVES_PER_EU) void ransac_kernel(Ransac
   int* result = A.result + (size_t)slot * 8;
   const float t = (float)(A.thr * A.thr);
 
+  if constexpr (M::MP_ALT > 0) if (count == M::MP_ALT) {
+    // solvePnPRansac with four correspondences: model_points = 4 == npoints -> solvePnP(SOLVEPNP_P3P) on all of them,
+    // every point an inlier, no RANSAC (calib3d/src/solvepnp.cpp)
+    if (tid == 0) {
+      float ms1[M::MP * M::PT1], ms2[M::MP * M::PT2];
+      for (int i = 0; i < M::MP_ALT * M::PT1; i++) ms1[i] = m1[i];
+      for (int i = 0; i < M::MP_ALT * M::PT2; i++) ms2[i] = m2[i];
+      double models[M::MS];
+      const int nm = M::solve_alt(A.P, ms1, ms2, models);
+      s_ctl[6] = nm > 0;
+      if (nm > 0)
+        for (int k = 0; k < M::MS; k++) out_model[k] = models[k];
+    }
+    __syncthreads();
+    const int ok = s_ctl[6];
+    for (int i = tid; i < count; i += RS_TT) mask[i] = ok ? 1 : 0;
+    if (tid == 0) { result[0] = ok; result[1] = ok ? count : 0; result[2] = 1; result[3] = 1; result[4] = 1; }
+    return;
+  }
   if (count < M::MP) {
     for (int i = tid; i < count; i += RS_TT) mask[i] = 0;
     if (tid == 0) { result[0] = 0; result[1] = 0; result[2] = 0; result[3] = 0; result[4] = 0; }
@@ -424,8 +443,8 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
   const int ok = result[0];
   const int count = min(max(result[5], 0), A.stride_pts);
   if (!ok) { if (tid == 0) result[6] = 0; return; }
-  if (A.n[slot] == 5) {
-    // solvePnPRansac with exactly model_points correspondences returns the EPnP solution as is
+  if (A.n[slot] == 5 || A.n[slot] == 4) {
+    // solvePnPRansac with exactly model_points correspondences returns the EPnP (5) / P3P (4) solution as is
     if (tid == 0) {
       const double* model = A.model + (size_t)slot * 16;
       for (int i = 0; i < 3; i++) { pose[i] = model[2 * i]; pose[3 + i] = model[2 * i + 1]; }
@@ -1043,7 +1062,7 @@ extern "C" int mvo_solve_pnp_ransac(mvo_ctx* ctx, const float* obj, const float*
                                     int* n_inliers) {
   if (!ctx || !obj || !img || !K || !rvec || !tvec || n < 0) return MVO_E_ARG;
   if (n_inliers) *n_inliers = 0;
-  if (n < 5) { ctx->set_error("solvePnPRansac: fewer than 5 points (P3P branch not built)"); return MVO_E_ARG; }
+  if (n < 4) { ctx->set_error("solvePnPRansac needs at least 4 correspondences"); return MVO_E_ARG; }
   GeomState* g = ctx->geom;
   int rc = upload_pairs(ctx, obj, 3, img, 2, n);
   if (rc) return rc;

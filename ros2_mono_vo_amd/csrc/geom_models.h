@@ -35,6 +35,7 @@ struct HModel {
   static constexpr int CH = 16, WS = 81 + 9 + 81;  // LtL, W, V
   static constexpr bool WIDE = false;
   static constexpr int LMEDS_BELOW = 0;
+  static constexpr int MP_ALT = 0;   // no second sample size
 
   __device__ static bool check_subset(const float* ms1, const float* ms2) {
     if (gl_have_collinear(ms1, 4) || gl_have_collinear(ms2, 4)) return false;
@@ -133,6 +134,7 @@ struct FModel {
   static constexpr int CH = 16, WS = 63 + 81 + 81 + 49;  // a, v, ta, tv
   static constexpr bool WIDE = true;
   static constexpr int LMEDS_BELOW = 15;  // findFundamentalMat: FM_RANSAC with fewer than 15 points runs LMedS (fundam.cpp)
+  static constexpr int MP_ALT = 0;   // no second sample size
 
   __device__ static bool check_subset(const float* ms1, const float* ms2) {
     return !gl_have_collinear(ms1, 7) && !gl_have_collinear(ms2, 7);
@@ -385,6 +387,394 @@ __device__ inline void gm_project_point(const double R[9], const double* dRdr, c
     }
   }
 }
+
+// ---------------------------------------------------------------------------------------------------
+// solvePnPRansac with exactly four correspondences (src/tracker.cpp:309 with min_tracked_points lowered to 4):
+// model_points = 4 == npoints, so OpenCV runs solvePnP(SOLVEPNP_P3P) on all four and returns them as inliers - no RANSAC,
+// no refinement.  solveP3P: undistortPoints -> p3p::solve (Gao's P3P: quartic by closed form, Horn alignment with a 4x4
+// Jacobi, the fourth point orders the solutions) -> smallest squared reprojection error over the four points.  Same IEEE
+// sequence as oracle/orc_p3p.inc (checked bit for bit on x86 by tests/test_sanitize_geom.py); cos / acos / pow come from
+// OCML on the device.
+// ---------------------------------------------------------------------------------------------------
+#define GM_P3_PI 3.1415926535897932384626433832795   // CV_PI
+
+__device__ GL_NOINLINE int gm_p3_solve_deg2(double a, double b, double c, double& x1, double& x2) {
+  double delta = b * b - 4 * a * c;
+  if (delta < 0) return 0;
+  double inv_2a = 0.5 / a;
+  if (delta == 0) {
+    x1 = -b * inv_2a;
+    x2 = x1;
+    return 1;
+  }
+  double sqrt_delta = sqrt(delta);
+  x1 = (-b + sqrt_delta) * inv_2a;
+  x2 = (-b - sqrt_delta) * inv_2a;
+  return 2;
+}
+
+__device__ GL_NOINLINE int gm_p3_solve_deg3(double a, double b, double c, double d, double& x0, double& x1, double& x2) {
+  if (a == 0) {
+    if (b == 0) {
+      if (c == 0) return 0;
+      x0 = -d / c;
+      return 1;
+    }
+    x2 = 0;
+    return gm_p3_solve_deg2(b, c, d, x0, x1);
+  }
+  double inv_a = 1. / a;
+  double b_a = inv_a * b, b_a2 = b_a * b_a;
+  double c_a = inv_a * c;
+  double d_a = inv_a * d;
+  double Q = (3 * c_a - b_a2) / 9;
+  double R = (9 * b_a * c_a - 27 * d_a - 2 * b_a * b_a2) / 54;
+  double Q3 = Q * Q * Q;
+  double D = Q3 + R * R;
+  double b_a_3 = (1. / 3.) * b_a;
+  if (Q == 0) {
+    if (R == 0) {
+      x0 = x1 = x2 = -b_a_3;
+      return 3;
+    } else {
+      x0 = pow(2 * R, 1 / 3.0) - b_a_3;
+      return 1;
+    }
+  }
+  if (D <= 0) {
+    double theta = acos(R / sqrt(-Q3));
+    double sqrt_Q = sqrt(-Q);
+    x0 = 2 * sqrt_Q * cos(theta / 3.0) - b_a_3;
+    x1 = 2 * sqrt_Q * cos((theta + 2 * GM_P3_PI) / 3.0) - b_a_3;
+    x2 = 2 * sqrt_Q * cos((theta + 4 * GM_P3_PI) / 3.0) - b_a_3;
+    return 3;
+  }
+  double AD = pow(fabs(R) + sqrt(D), 1.0 / 3.0) * (R > 0 ? 1 : (R < 0 ? -1 : 0));
+  double BD = (AD == 0) ? 0 : -Q / AD;
+  x0 = AD + BD - b_a_3;
+  return 1;
+}
+
+__device__ GL_NOINLINE int gm_p3_solve_deg4(double a, double b, double c, double d, double e, double& x0, double& x1, double& x2, double& x3) {
+  if (a == 0) {
+    x3 = 0;
+    return gm_p3_solve_deg3(b, c, d, e, x0, x1, x2);
+  }
+  double inv_a = 1. / a;
+  b *= inv_a; c *= inv_a; d *= inv_a; e *= inv_a;
+  double b2 = b * b, bc = b * c, b3 = b2 * b;
+  double r0, r1, r2;
+  int n = gm_p3_solve_deg3(1, -c, d * b - 4 * e, 4 * c * e - d * d - b2 * e, r0, r1, r2);
+  if (n == 0) return 0;
+  double R2 = 0.25 * b2 - c + r0, R;
+  if (R2 < 0) return 0;
+  R = sqrt(R2);
+  double inv_R = 1. / R;
+  int nb_real_roots = 0;
+  double D2, E2;
+  if (R < 10E-12) {
+    double temp = r0 * r0 - 4 * e;
+    if (temp < 0)
+      D2 = E2 = -1;
+    else {
+      double sqrt_temp = sqrt(temp);
+      D2 = 0.75 * b2 - 2 * c + 2 * sqrt_temp;
+      E2 = D2 - 4 * sqrt_temp;
+    }
+  } else {
+    double u = 0.75 * b2 - 2 * c - R2, v = 0.25 * inv_R * (4 * bc - 8 * d - b3);
+    D2 = u + v;
+    E2 = u - v;
+  }
+  double b_4 = 0.25 * b, R_2 = 0.5 * R;
+  if (D2 >= 0) {
+    double D = sqrt(D2);
+    nb_real_roots = 2;
+    double D_2 = 0.5 * D;
+    x0 = R_2 + D_2 - b_4;
+    x1 = x0 - D;
+  }
+  if (E2 >= 0) {
+    double E = sqrt(E2);
+    double E_2 = 0.5 * E;
+    if (nb_real_roots == 0) {
+      x0 = -R_2 + E_2 - b_4;
+      x1 = x0 - E;
+      nb_real_roots = 2;
+    } else {
+      x2 = -R_2 + E_2 - b_4;
+      x3 = x2 - E;
+      nb_real_roots = 4;
+    }
+  }
+  return nb_real_roots;
+}
+
+// p3p::jacobi_4x4: cyclic Jacobi, A symmetric 4x4 (upper triangle used), D eigenvalues, U eigenvectors in columns
+__device__ GL_NOINLINE bool gm_p3_jacobi_4x4(double* A, double* D, double* U) {
+  double B[4] = {}, Z[4] = {};
+  double Id[16] = {1., 0., 0., 0., 0., 1., 0., 0., 0., 0., 1., 0., 0., 0., 0., 1.};
+  for (int i = 0; i < 16; i++) U[i] = Id[i];
+  B[0] = A[0]; B[1] = A[5]; B[2] = A[10]; B[3] = A[15];
+  for (int i = 0; i < 4; i++) D[i] = B[i];
+  for (int iter = 0; iter < 50; iter++) {
+    double sum = fabs(A[1]) + fabs(A[2]) + fabs(A[3]) + fabs(A[6]) + fabs(A[7]) + fabs(A[11]);
+    if (sum == 0.0) return true;
+    double tresh = (iter < 3) ? 0.2 * sum / 16. : 0.0;
+    for (int i = 0; i < 3; i++) {
+      double* pAij = A + 5 * i + 1;
+      for (int j = i + 1; j < 4; j++) {
+        double Aij = *pAij;
+        double eps_machine = 100.0 * fabs(Aij);
+        if (iter > 3 && fabs(D[i]) + eps_machine == fabs(D[i]) && fabs(D[j]) + eps_machine == fabs(D[j]))
+          *pAij = 0.0;
+        else if (fabs(Aij) > tresh) {
+          double hh = D[j] - D[i], t;
+          if (fabs(hh) + eps_machine == fabs(hh))
+            t = Aij / hh;
+          else {
+            double theta = 0.5 * hh / Aij;
+            t = 1.0 / (fabs(theta) + sqrt(1.0 + theta * theta));
+            if (theta < 0.0) t = -t;
+          }
+          hh = t * Aij;
+          Z[i] -= hh;
+          Z[j] += hh;
+          D[i] -= hh;
+          D[j] += hh;
+          *pAij = 0.0;
+          double c = 1.0 / sqrt(1 + t * t);
+          double s = t * c;
+          double tau = s / (1.0 + c);
+          for (int k = 0; k <= i - 1; k++) {
+            double g = A[k * 4 + i], h = A[k * 4 + j];
+            A[k * 4 + i] = g - s * (h + g * tau);
+            A[k * 4 + j] = h + s * (g - h * tau);
+          }
+          for (int k = i + 1; k <= j - 1; k++) {
+            double g = A[i * 4 + k], h = A[k * 4 + j];
+            A[i * 4 + k] = g - s * (h + g * tau);
+            A[k * 4 + j] = h + s * (g - h * tau);
+          }
+          for (int k = j + 1; k < 4; k++) {
+            double g = A[i * 4 + k], h = A[j * 4 + k];
+            A[i * 4 + k] = g - s * (h + g * tau);
+            A[j * 4 + k] = h + s * (g - h * tau);
+          }
+          for (int k = 0; k < 4; k++) {
+            double g = U[k * 4 + i], h = U[k * 4 + j];
+            U[k * 4 + i] = g - s * (h + g * tau);
+            U[k * 4 + j] = h + s * (g - h * tau);
+          }
+        }
+        pAij++;
+      }
+    }
+    for (int i = 0; i < 4; i++) B[i] += Z[i];
+    for (int i = 0; i < 4; i++) D[i] = B[i];
+    for (int i = 0; i < 4; i++) Z[i] = 0;
+  }
+  return false;
+}
+
+// p3p::align: rigid motion taking (X_i, Y_i, Z_i) onto M_end[i] (Horn 1987, unit quaternion = top eigenvector of Qs)
+__device__ GL_NOINLINE bool gm_p3_align(double M_end[3][3], double X0, double Y0, double Z0, double X1, double Y1, double Z1, double X2, double Y2,
+                     double Z2, double R[3][3], double T[3]) {
+  double C_start[3] = {}, C_end[3] = {};
+  for (int i = 0; i < 3; i++) C_end[i] = (M_end[0][i] + M_end[1][i] + M_end[2][i]) / 3;
+  C_start[0] = (X0 + X1 + X2) / 3;
+  C_start[1] = (Y0 + Y1 + Y2) / 3;
+  C_start[2] = (Z0 + Z1 + Z2) / 3;
+  double s[3 * 3] = {};
+  for (int j = 0; j < 3; j++) {
+    s[0 * 3 + j] = (X0 * M_end[0][j] + X1 * M_end[1][j] + X2 * M_end[2][j]) / 3 - C_end[j] * C_start[0];
+    s[1 * 3 + j] = (Y0 * M_end[0][j] + Y1 * M_end[1][j] + Y2 * M_end[2][j]) / 3 - C_end[j] * C_start[1];
+    s[2 * 3 + j] = (Z0 * M_end[0][j] + Z1 * M_end[1][j] + Z2 * M_end[2][j]) / 3 - C_end[j] * C_start[2];
+  }
+  double Qs[16] = {}, evs[4] = {}, U[16] = {};
+  Qs[0 * 4 + 0] = s[0 * 3 + 0] + s[1 * 3 + 1] + s[2 * 3 + 2];
+  Qs[1 * 4 + 1] = s[0 * 3 + 0] - s[1 * 3 + 1] - s[2 * 3 + 2];
+  Qs[2 * 4 + 2] = s[1 * 3 + 1] - s[2 * 3 + 2] - s[0 * 3 + 0];
+  Qs[3 * 4 + 3] = s[2 * 3 + 2] - s[0 * 3 + 0] - s[1 * 3 + 1];
+  Qs[1 * 4 + 0] = Qs[0 * 4 + 1] = s[1 * 3 + 2] - s[2 * 3 + 1];
+  Qs[2 * 4 + 0] = Qs[0 * 4 + 2] = s[2 * 3 + 0] - s[0 * 3 + 2];
+  Qs[3 * 4 + 0] = Qs[0 * 4 + 3] = s[0 * 3 + 1] - s[1 * 3 + 0];
+  Qs[2 * 4 + 1] = Qs[1 * 4 + 2] = s[1 * 3 + 0] + s[0 * 3 + 1];
+  Qs[3 * 4 + 1] = Qs[1 * 4 + 3] = s[2 * 3 + 0] + s[0 * 3 + 2];
+  Qs[3 * 4 + 2] = Qs[2 * 4 + 3] = s[2 * 3 + 1] + s[1 * 3 + 2];
+  gm_p3_jacobi_4x4(Qs, evs, U);
+  int i_ev = 0;
+  double ev_max = evs[i_ev];
+  for (int i = 1; i < 4; i++)
+    if (evs[i] > ev_max) ev_max = evs[i_ev = i];
+  double q[4];
+  for (int i = 0; i < 4; i++) q[i] = U[i * 4 + i_ev];
+  double q02 = q[0] * q[0], q12 = q[1] * q[1], q22 = q[2] * q[2], q32 = q[3] * q[3];
+  double q0_1 = q[0] * q[1], q0_2 = q[0] * q[2], q0_3 = q[0] * q[3];
+  double q1_2 = q[1] * q[2], q1_3 = q[1] * q[3];
+  double q2_3 = q[2] * q[3];
+  R[0][0] = q02 + q12 - q22 - q32;
+  R[0][1] = 2. * (q1_2 - q0_3);
+  R[0][2] = 2. * (q1_3 + q0_2);
+  R[1][0] = 2. * (q1_2 + q0_3);
+  R[1][1] = q02 + q22 - q12 - q32;
+  R[1][2] = 2. * (q2_3 - q0_1);
+  R[2][0] = 2. * (q1_3 - q0_2);
+  R[2][1] = 2. * (q2_3 + q0_1);
+  R[2][2] = q02 + q32 - q12 - q22;
+  for (int i = 0; i < 3; i++) T[i] = C_end[i] - (R[i][0] * C_start[0] + R[i][1] * C_start[1] + R[i][2] * C_start[2]);
+  return true;
+}
+
+// p3p::solve_for_lengths: |PA|, |PB|, |PC| from the pairwise distances |BC|, |AC|, |AB| and the cosines of the angles
+// at the projection centre; up to four solutions (main branch of Gao et al.)
+__device__ GL_NOINLINE int gm_p3_solve_for_lengths(double lengths[4][3], double distances[3], double cosines[3]) {
+  double p = cosines[0] * 2;
+  double q = cosines[1] * 2;
+  double r = cosines[2] * 2;
+  double inv_d22 = 1. / (distances[2] * distances[2]);
+  double a = inv_d22 * (distances[0] * distances[0]);
+  double b = inv_d22 * (distances[1] * distances[1]);
+  double a2 = a * a, b2 = b * b, p2 = p * p, q2 = q * q, r2 = r * r;
+  double pr = p * r, pqr = q * pr;
+  if (p2 + q2 + r2 - pqr - 1 == 0) return 0;
+  double ab = a * b, a_2 = 2 * a;
+  double A = -2 * b + b2 + a2 + 1 + ab * (2 - r2) - a_2;
+  if (A == 0) return 0;
+  double a_4 = 4 * a;
+  double B = q * (-2 * (ab + a2 + 1 - b) + r2 * ab + a_4) + pr * (b - b2 + ab);
+  double C = q2 + b2 * (r2 + p2 - 2) - b * (p2 + pqr) - ab * (r2 + pqr) + (a2 - a_2) * (2 + q2) + 2;
+  double D = pr * (ab - b2 + b) + q * ((p2 - 2) * b + 2 * (ab - a2) + a_4 - 2);
+  double E = 1 + 2 * (b - a - ab) + b2 - b * p2 + a2;
+  double temp = (p2 * (a - 1 + b) + r2 * (a - 1 - b) + pqr - a * pqr);
+  double b0 = b * temp * temp;
+  if (b0 == 0) return 0;
+  double real_roots[4];
+  int n = gm_p3_solve_deg4(A, B, C, D, E, real_roots[0], real_roots[1], real_roots[2], real_roots[3]);
+  if (n == 0) return 0;
+  int nb_solutions = 0;
+  double r3 = r2 * r, pr2 = p * r2, r3q = r3 * q;
+  double inv_b0 = 1. / b0;
+  for (int i = 0; i < n; i++) {
+    double x = real_roots[i];
+    if (x <= 0) continue;
+    double x2 = x * x;
+    double b1 = ((1 - a - b) * x2 + (q * a - q) * x + 1 - a + b) *
+                (((r3 * (a2 + ab * (2 - r2) - a_2 + b2 - 2 * b + 1)) * x +
+                  (r3q * (2 * (b - a2) + a_4 + ab * (r2 - 2) - 2) + pr2 * (1 + a2 + 2 * (ab - a - b) + r2 * (b - b2) + b2))) * x2 +
+                 (r3 * (q2 * (1 - 2 * a + a2) + r2 * (b2 - ab) - a_4 + 2 * (a2 - b2) + 2) + r * p2 * (b2 + 2 * (ab - b - a) + 1 + a2) +
+                  pr2 * q * (a_4 + 2 * (b - ab - a2) - 2 - r2 * b)) * x +
+                 2 * r3q * (a_2 - b - a2 + ab - 1) + pr2 * (q2 - a_4 + 2 * (a2 - b2) + r2 * b + q2 * (a2 - a_2) + 2) +
+                 p2 * (p * (2 * (ab - a - b) + a2 + b2 + 1) + 2 * q * r * (b + a_2 - a2 - ab - 1)));
+    if (b1 <= 0) continue;
+    double y = inv_b0 * b1;
+    double v = x2 + y * y - x * y * r;
+    if (v <= 0) continue;
+    double Z = distances[2] / sqrt(v);
+    double X = x * Z;
+    double Y = y * Z;
+    lengths[nb_solutions][0] = X;
+    lengths[nb_solutions][1] = Y;
+    lengths[nb_solutions][2] = Z;
+    nb_solutions++;
+  }
+  return nb_solutions;
+}
+
+// p3p::solve with p4p = true.  mu, mv: pixel coordinates (the undistorted normalised point times fx plus cx, as
+// p3p::extract_points forms them); X, Y, Z: object points.
+__device__ GL_NOINLINE int gm_p3_solve(const CamK& cam, double R[4][3][3], double t[4][3], const double mu_[4], const double mv_[4], const double X[4],
+                    const double Y[4], const double Z[4]) {
+  const double inv_fx = 1. / cam.fx, inv_fy = 1. / cam.fy, cx_fx = cam.cx / cam.fx, cy_fy = cam.cy / cam.fy;
+  double mu[4], mv[4], mk[3];
+  for (int i = 0; i < 3; i++) {
+    mu[i] = inv_fx * mu_[i] - cx_fx;
+    mv[i] = inv_fy * mv_[i] - cy_fy;
+    double norm = sqrt(mu[i] * mu[i] + mv[i] * mv[i] + 1);
+    mk[i] = 1. / norm; mu[i] *= mk[i]; mv[i] *= mk[i];
+  }
+  mu[3] = inv_fx * mu_[3] - cx_fx;
+  mv[3] = inv_fy * mv_[3] - cy_fy;
+  double distances[3];
+  distances[0] = sqrt((X[1] - X[2]) * (X[1] - X[2]) + (Y[1] - Y[2]) * (Y[1] - Y[2]) + (Z[1] - Z[2]) * (Z[1] - Z[2]));
+  distances[1] = sqrt((X[0] - X[2]) * (X[0] - X[2]) + (Y[0] - Y[2]) * (Y[0] - Y[2]) + (Z[0] - Z[2]) * (Z[0] - Z[2]));
+  distances[2] = sqrt((X[0] - X[1]) * (X[0] - X[1]) + (Y[0] - Y[1]) * (Y[0] - Y[1]) + (Z[0] - Z[1]) * (Z[0] - Z[1]));
+  double cosines[3];
+  cosines[0] = mu[1] * mu[2] + mv[1] * mv[2] + mk[1] * mk[2];
+  cosines[1] = mu[0] * mu[2] + mv[0] * mv[2] + mk[0] * mk[2];
+  cosines[2] = mu[0] * mu[1] + mv[0] * mv[1] + mk[0] * mk[1];
+  double lengths[4][3] = {};
+  int n = gm_p3_solve_for_lengths(lengths, distances, cosines);
+  int nb_solutions = 0;
+  double reproj_errors[4];
+  for (int i = 0; i < n; i++) {
+    double M_orig[3][3];
+    for (int k = 0; k < 3; k++) {
+      M_orig[k][0] = lengths[i][k] * mu[k];
+      M_orig[k][1] = lengths[i][k] * mv[k];
+      M_orig[k][2] = lengths[i][k] * mk[k];
+    }
+    if (!gm_p3_align(M_orig, X[0], Y[0], Z[0], X[1], Y[1], Z[1], X[2], Y[2], Z[2], R[nb_solutions], t[nb_solutions])) continue;
+    {
+      double(*Rn)[3] = R[nb_solutions];
+      double* tn = t[nb_solutions];
+      double X3p = Rn[0][0] * X[3] + Rn[0][1] * Y[3] + Rn[0][2] * Z[3] + tn[0];
+      double Y3p = Rn[1][0] * X[3] + Rn[1][1] * Y[3] + Rn[1][2] * Z[3] + tn[1];
+      double Z3p = Rn[2][0] * X[3] + Rn[2][1] * Y[3] + Rn[2][2] * Z[3] + tn[2];
+      double mu3p = X3p / Z3p;
+      double mv3p = Y3p / Z3p;
+      reproj_errors[nb_solutions] = (mu3p - mu[3]) * (mu3p - mu[3]) + (mv3p - mv[3]) * (mv3p - mv[3]);
+    }
+    nb_solutions++;
+  }
+  for (int i = 1; i < nb_solutions; i++)
+    for (int j = i; j > 0 && reproj_errors[j - 1] > reproj_errors[j]; j--) {
+      { double tmp_ = reproj_errors[j]; reproj_errors[j] = reproj_errors[j - 1]; reproj_errors[j - 1] = tmp_; }
+      for (int k = 0; k < 9; k++) { double tmp_ = R[j][k / 3][k % 3]; R[j][k / 3][k % 3] = R[j - 1][k / 3][k % 3]; R[j - 1][k / 3][k % 3] = tmp_; }
+      for (int k = 0; k < 3; k++) { double tmp_ = t[j][k]; t[j][k] = t[j - 1][k]; t[j - 1][k] = tmp_; }
+    }
+  return nb_solutions;
+}
+
+// solvePnP(SOLVEPNP_P3P) on four float correspondences -> rvec, tvec of the solution with the smallest squared
+// reprojection error over the four points.  Returns the number of solutions (0: solvePnPRansac returns false).
+__device__ GL_NOINLINE int gm_p3p4(const float* obj, const float* img, const CamK& cam, double rvec[3], double tvec[3]) {
+  double mu[4], mv[4], X[4], Y[4], Z[4];
+  for (int i = 0; i < 4; i++) {
+    double xu, yu;
+    gm_undistort_point(cam, (double)img[2 * i], (double)img[2 * i + 1], xu, yu);   // cvUndistortPoints writes CV_32FC2
+    float xn = (float)xu, yn = (float)yu;
+    mu[i] = xn * cam.fx + cam.cx;   // p3p::extract_points
+    mv[i] = yn * cam.fy + cam.cy;
+    X[i] = obj[3 * i]; Y[i] = obj[3 * i + 1]; Z[i] = obj[3 * i + 2];
+  }
+  double Rs[4][3][3] = {}, ts[4][3] = {};
+  int solutions = gm_p3_solve(cam, Rs, ts, mu, mv, X, Y, Z);
+  if (solutions == 0) return 0;
+  double rv[4][3], errs[4];
+  int order[4] = {0, 1, 2, 3};
+  for (int s = 0; s < solutions; s++) {
+    double Rm[9];
+    for (int k = 0; k < 9; k++) Rm[k] = Rs[s][k / 3][k % 3];
+    gm_rodrigues_m2v(Rm, rv[s]);
+    double R2[9];
+    gm_rodrigues_v2m(rv[s], R2, nullptr);   // projectPoints starts from the rotation vector
+    double e = 0;
+    for (int i = 0; i < 4; i++) {
+      double M[3] = {X[i], Y[i], Z[i]}, m[2];
+      gm_project_point(R2, nullptr, ts[s], cam, M, m, nullptr, nullptr);
+      double ex = (double)img[2 * i] - m[0], ey = (double)img[2 * i + 1] - m[1];
+      e += ex * ex;
+      e += ey * ey;
+    }
+    errs[s] = e;
+  }
+  for (int i = 1; i < solutions; i++)
+    for (int j = i; j > 0 && errs[j - 1] > errs[j]; j--) { double te_ = errs[j]; errs[j] = errs[j - 1]; errs[j - 1] = te_; int to_ = order[j]; order[j] = order[j - 1]; order[j - 1] = to_; }
+  for (int k = 0; k < 3; k++) { rvec[k] = rv[order[0]][k]; tvec[k] = ts[order[0]][k]; }
+  return solutions;
+}
+
 
 // ---------------------------------------------------------------------------------------------------
 // EPnP on 5 points (epnp.cpp) — the solvePnPRansac minimal kernel
@@ -707,6 +1097,13 @@ struct PnPModel {
   static constexpr int CH = 20, WS = 144 + 132 + 12;  // MtM -> Ut; M (120), then dv + L (132) / the small solves' workspaces; singular values
   static constexpr bool WIDE = false;
   static constexpr int LMEDS_BELOW = 0;
+  static constexpr int MP_ALT = 4;   // four correspondences: P3P on all of them instead of RANSAC
+  __device__ static int solve_alt(const ModelParams& P, const float* ms1, const float* ms2, double* model) {
+    double rvec[3], tvec[3];
+    if (gm_p3p4(ms1, ms2, P.cam, rvec, tvec) == 0) return 0;
+    for (int i = 0; i < 3; i++) { model[2 * i] = rvec[i]; model[2 * i + 1] = tvec[i]; }  // hconcat(rvec, tvec)
+    return 1;
+  }
   __device__ static bool check_subset(const float*, const float*) { return true; }
   __device__ static int solve(const ModelParams& P, const float* ms1, const float* ms2, double* model, double* ws) {
     double rvec[3], tvec[3];
@@ -955,6 +1352,7 @@ struct EModel {
   static constexpr int CH = 64, WS = 0;  // initialisation only (src/initializer.cpp), not on the per-frame path: private memory
   static constexpr bool WIDE = true;
   static constexpr int LMEDS_BELOW = 0;
+  static constexpr int MP_ALT = 0;   // no second sample size
   __device__ static bool check_subset(const float*, const float*) { return true; }
   __device__ static int solve(const ModelParams& P, const float* ms1, const float* ms2, double* models, double*) {
     double q1[10], q2[10];

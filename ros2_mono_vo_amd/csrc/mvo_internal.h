@@ -238,6 +238,7 @@ void pipe_state_destroy(mvo_ctx* ctx);
 void trk_destroy(mvo_ctx* ctx);   // track.hip
 int trk_reset(mvo_ctx* ctx);
 int trk_wait_upload(mvo_ctx* ctx, int frame_idx);   // ctx->stream waits for an asynchronous upload into ring entry frame_idx
+int trk_output_seed(mvo_ctx* ctx, int slot, const float* d_lm, int n);   // output side: the seed landmarks open the slot's map
 int trk_sync_upload(mvo_ctx* ctx);                  // host waits for the upload stream
 void lk_filter_compact_launch(mvo_ctx* ctx, hipStream_t st);   // pipeline.hip: status/err filter of all slots
 

@@ -477,6 +477,8 @@ extern "C" int mvo_batch_set_landmarks(mvo_ctx* ctx, int slot, const float* xyz,
   MVO_HIP(hipMemcpyAsync(p->d_lm + o * 3, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   MVO_HIP(hipMemcpyAsync(p->d_kf_lm + o * 3, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   MVO_HIP(hipMemsetAsync(p->d_kf_has + o, 1, (size_t)n, ctx->stream));
+  int rc = trk_output_seed(ctx, slot, p->d_lm + o * 3, n);   // output side enabled: the seed landmarks open the slot's map
+  if (rc) return rc;
   MVO_HIP(hipStreamSynchronize(ctx->stream));
   return MVO_OK;
 }

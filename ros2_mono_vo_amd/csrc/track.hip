@@ -45,11 +45,20 @@ struct TrackState {
                                // 2: never a key-frame (the always-on part of the step: LK + PnP)
   bool pending = false;
   hipEvent_t ev_done = nullptr;
+  // output side (mvo_batch_enable_output): what MonoVO::image_callback derives from the tracker's result on every frame
+  bool out_on = false;
+  int map_cap = 0, path_cap = 0;
+  float* d_cloud = nullptr;        // [B][map_cap][3] the slot's Map as PointCloud2 payload: (z, -x, -y) float32 per landmark, id order
+  int* d_n_cloud = nullptr;        // [B]
+  double* d_path = nullptr;        // [B][path_cap][7] nav_msgs/Path poses: position xyz, orientation xyzw
+  int* d_n_path = nullptr;         // [B]
+  mvo_ros_pose* d_ros = nullptr;   // [B] last_pose_ in REP-103 + tracking_valid_
 };
 
 #define TRK_ERR_KEYPOINTS 1   // a slot's key-points exceeded max_points (clamped)
 #define TRK_ERR_CAND 2        // FAST candidates exceeded the candidate capacity (clamped)
 #define TRK_ERR_KPCAP 4       // dense key-point capacity exceeded (clamped)
+#define TRK_ERR_MAPCAP 8      // a slot's landmark cloud or path exceeded its capacity (entries beyond it dropped)
 
 // ---------------------------------------------------------------------------------------------------
 // kernels
@@ -291,6 +300,125 @@ __global__ void trk_orb_capcheck_kernel(const int* __restrict__ slot_base, const
   }
 }
 
+// ---- output side (src/mono_vo.cpp:117-152, src/utils.cpp:85-243), per slot on the device --------------------------
+// Map::add_landmark of Tracker::add_new_keyframe (src/tracker.cpp:211-227): matches are visited in order; a valid
+// (cheirality) match whose key-frame observation has no landmark yet creates one, and Map::get_landmark_points returns
+// them in id = creation order (std::map<long, Landmark>).  The slot's cloud is that list already in the wire format of
+// points3d_to_pointcloud_msg (src/utils.cpp:229-237): ROS x = cv z, y = -cv x, z = -cv y, three float32 per point.
+// Runs before trk_assign_promote_kernel (which overwrites the key-frame's landmark flags), one workgroup per list entry.
+__global__ __launch_bounds__(1024) void trk_map_append_kernel(const int* __restrict__ kf_list, const int* __restrict__ nkf,
+                                                              const mvo_match* __restrict__ matches, const int* __restrict__ n_matches,
+                                                              const u8* __restrict__ tri_ok, const float* __restrict__ tri,
+                                                              const u8* __restrict__ kf_has, int cap, float* __restrict__ cloud,
+                                                              int* __restrict__ n_cloud, int map_cap, int* __restrict__ err) {
+  __shared__ int s_wave[16];
+  __shared__ int s_base;
+  if ((int)blockIdx.x >= *nkf) return;
+  const int slot = kf_list[blockIdx.x], lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nm = min(max(n_matches[slot], 0), cap);
+  const size_t b = (size_t)slot * cap;
+  float* out = cloud + (size_t)slot * map_cap * 3;
+  if (threadIdx.x == 0) s_base = n_cloud[slot];
+  __syncthreads();
+  for (int i0 = 0; i0 < nm; i0 += 1024) {
+    const int i = i0 + threadIdx.x;
+    const bool add = i < nm && tri_ok[b + i] && !kf_has[b + matches[b + i].query_idx];
+    const unsigned long long m = __ballot(add);
+    const int pre = __popcll(m & ((1ull << lane) - 1));
+    if (lane == 0) s_wave[wave] = __popcll(m);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wave; w++) off += s_wave[w];
+    if (add) {
+      const int o = off + pre;
+      if (o < map_cap) { out[3 * o] = tri[3 * (b + i) + 2]; out[3 * o + 1] = -tri[3 * (b + i)]; out[3 * o + 2] = -tri[3 * (b + i) + 1]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int tt = 0;
+      for (int w = 0; w < 16; w++) tt += s_wave[w];
+      s_base += tt;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (s_base > map_cap) { atomicOr(err, TRK_ERR_MAPCAP); s_base = map_cap; }
+    n_cloud[slot] = s_base;
+  }
+}
+
+// affine3d_to_odometry_msg (src/utils.cpp:85-129): camera pose pose_wc = (R_cw, t_cw)^-1 conjugated into REP-103 with
+// M = [0 0 1; -1 0 0; 0 -1 0], quaternion by tf2::Matrix3x3::getRotation + normalize.
+__device__ inline void trk_pose_cw_to_ros(const double* pose_cw /* rvec, tvec */, double pos[3], double q[4]) {
+  double R[9];
+  trk_rodrigues(pose_cw, R);
+  const double* t = pose_cw + 3;
+  // pose_wc: R_wc = R^T, t_wc = -R^T t
+  double Rw[9], tw[3];
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) Rw[3 * i + j] = R[3 * j + i];
+    tw[i] = -(R[i] * t[0] + R[3 + i] * t[1] + R[6 + i] * t[2]);
+  }
+  // M Rw M^T: row / column permutation with signs; ros axes (x, y, z) = cv (z, -x, -y)
+  const int ax[3] = {2, 0, 1};
+  const double sg[3] = {1.0, -1.0, -1.0};
+  double m[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) m[3 * i + j] = sg[i] * sg[j] * Rw[3 * ax[i] + ax[j]];
+  for (int i = 0; i < 3; i++) pos[i] = sg[i] * tw[ax[i]];
+  const double trace = m[0] + m[4] + m[8];
+  double x, y, z, w;
+  if (trace > 0.0) {
+    double s = sqrt(trace + 1.0);
+    w = s * 0.5;
+    s = 0.5 / s;
+    x = (m[7] - m[5]) * s; y = (m[2] - m[6]) * s; z = (m[3] - m[1]) * s;
+  } else {
+    const int i = m[0] < m[4] ? (m[4] < m[8] ? 2 : 1) : (m[0] < m[8] ? 2 : 0);
+    const int j = (i + 1) % 3, k = (i + 2) % 3;
+    double s = sqrt(m[4 * i] - m[4 * j] - m[4 * k] + 1.0);
+    double v[3];
+    v[i] = s * 0.5;
+    s = 0.5 / s;
+    w = (m[3 * k + j] - m[3 * j + k]) * s;
+    v[j] = (m[3 * j + i] + m[3 * i + j]) * s;
+    v[k] = (m[3 * k + i] + m[3 * i + k]) * s;
+    x = v[0]; y = v[1]; z = v[2];
+  }
+  const double n = sqrt(x * x + y * y + z * z + w * w);
+  q[0] = x / n; q[1] = y / n; q[2] = z / n; q[3] = w / n;
+}
+
+// The pose bookkeeping of MonoVO::image_callback (src/mono_vo.cpp:119-148) for every slot after its Tracker::update: LOST ->
+// tracking_valid_ = false and the last pose is kept; a returned pose becomes last_pose_ (tracking_valid_ = true); while
+// tracking is valid one PoseStamped goes onto the path.  An ABORTED slot (the reference process would have died in
+// cv::Rodrigues) is frozen: no update, no path entry.
+__global__ __launch_bounds__(256) void trk_output_kernel(const int* __restrict__ state, const int* __restrict__ flags, const double* __restrict__ pose,
+                                                         int B, mvo_ros_pose* __restrict__ ros, double* __restrict__ path, int* __restrict__ n_path,
+                                                         int path_cap, int* __restrict__ err) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= B) return;
+  const int st = state[s];
+  if (st == MVO_TRACK_ABORTED) return;
+  mvo_ros_pose r = ros[s];
+  if (st == MVO_TRACK_LOST) r.tracking_valid = 0;
+  else if (flags[s] & MVO_STEP_POSE) {
+    trk_pose_cw_to_ros(pose + 8 * s, r.position, r.orientation);
+    r.tracking_valid = 1;
+    r.has_pose = 1;
+  }
+  ros[s] = r;
+  if (r.tracking_valid && r.has_pose) {
+    const int n = n_path[s];
+    if (n < path_cap) {
+      double* o = path + ((size_t)s * path_cap + n) * 7;
+      for (int k = 0; k < 3; k++) o[k] = r.position[k];
+      for (int k = 0; k < 4; k++) o[3 + k] = r.orientation[k];
+      n_path[s] = n + 1;
+    } else atomicOr(err, TRK_ERR_MAPCAP);
+  }
+}
+
 // ---- landmark hand-over of Tracker::add_new_keyframe (src/tracker.cpp:211-227) over the key-frame list ------------
 // Matches are visited in order in the reference, so when several share a train index the LAST valid one decides that
 // key-point's landmark: winner[t] = max valid match index (phase 1), then per key-point take the winner (phase 2).
@@ -478,6 +606,8 @@ void trk_destroy(mvo_ctx* ctx) {
   void* dev[] = {t->d_state, t->d_count, t->d_flags, t->d_n_pnp, t->d_n_hf, t->d_kf_list, t->d_nkf, t->d_pt_base, t->d_work_slot,
                  t->d_work_ctr, t->d_err, t->d_mask_f, t->d_model_f, t->d_result_f, t->d_res};
   for (void* q : dev) (void)hipFree(q);
+  void* outb[] = {t->d_cloud, t->d_n_cloud, t->d_path, t->d_n_path, t->d_ros};
+  for (void* q : outb) if (q) (void)hipFree(q);
   if (t->h_res) (void)hipHostFree(t->h_res);
   if (t->h_err) (void)hipHostFree(t->h_err);
   if (t->ev_done) (void)hipEventDestroy(t->ev_done);
@@ -636,6 +766,9 @@ extern "C" int mvo_batch_track_async(mvo_ctx* ctx, int frame_idx) {
                              p->d_tri_ok, t->d_kf_list, t->d_nkf);
     hipLaunchKernelGGL(trk_winner_clear_kernel, dim3(4, B), dim3(256), 0, st, t->d_kf_list, t->d_nkf, m->d_nt, cap, p->d_winner);
     hipLaunchKernelGGL(trk_winner_kernel, dim3(4, B), dim3(256), 0, st, m->d_out, m->d_nout, p->d_tri_ok, cap, t->d_kf_list, t->d_nkf, p->d_winner);
+    if (t->out_on)
+      hipLaunchKernelGGL(trk_map_append_kernel, dim3(B), dim3(1024), 0, st, t->d_kf_list, t->d_nkf, m->d_out, m->d_nout, p->d_tri_ok, p->d_tri,
+                         p->d_kf_has, cap, t->d_cloud, t->d_n_cloud, t->map_cap, t->d_err);
     hipLaunchKernelGGL(trk_assign_promote_kernel, dim3(B), dim3(1024), 0, st, t->d_kf_list, t->d_nkf, m->d_out, p->d_winner, m->d_nt, p->d_kp_xy,
                        p->d_kf_has, p->d_kf_lm, p->d_tri, p->d_tri_ok, m->d_nout, cap, p->d_cur_has, p->d_cur_lmk, ctx->d_prev_pts, p->d_lm,
                        p->d_kf_pts, ctx->d_npts, p->d_kfkp_xy, m->d_q, m->d_t, m->d_nq, p->d_kf_pose, g->d_pose, t->d_count, t->d_res);
@@ -643,6 +776,9 @@ extern "C" int mvo_batch_track_async(mvo_ctx* ctx, int frame_idx) {
   // ---- prev_frame_ = new_frame for the others; results -------------------------------------------------------------------
   hipLaunchKernelGGL(trk_finalize_kernel, dim3(B), dim3(256), 0, st, t->d_state, t->d_count, t->d_flags, p->d_ncur, cap, p->d_cur_pts,
                      p->d_cur_lm, p->d_cur_kf, ctx->d_prev_pts, p->d_lm, p->d_kf_pts, ctx->d_npts, t->d_res);
+  if (t->out_on)
+    hipLaunchKernelGGL(trk_output_kernel, dim3(nb), dim3(256), 0, st, t->d_state, t->d_flags, g->d_pose, B, t->d_ros, t->d_path, t->d_n_path,
+                       t->path_cap, t->d_err);
   MVO_HIP(hipMemcpyAsync(t->h_res, t->d_res, (size_t)B * sizeof(mvo_step_result), hipMemcpyDeviceToHost, st));
   MVO_HIP(hipMemcpyAsync(t->h_err, t->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
   MVO_HIP(hipEventRecord(t->ev_done, st));
@@ -669,7 +805,7 @@ extern "C" int mvo_batch_track_wait(mvo_ctx* ctx, mvo_step_result* out) {
   if (*t->h_err) {
     const int e = *t->h_err;
     ctx->set_error(std::string("mvo_batch_track: device capacity exceeded (") + ((e & TRK_ERR_KEYPOINTS) ? "key-points > max_points " : "") +
-                   ((e & TRK_ERR_CAND) ? "FAST candidates " : "") + ((e & TRK_ERR_KPCAP) ? "dense key-points" : "") + ")");
+                   ((e & TRK_ERR_CAND) ? "FAST candidates " : "") + ((e & TRK_ERR_KPCAP) ? "dense key-points " : "") + ((e & TRK_ERR_MAPCAP) ? "landmark cloud / path capacity" : "") + ")");
     MVO_HIP(hipMemsetAsync(t->d_err, 0, sizeof(int), ctx->stream));
     return MVO_E_CAPACITY;
   }
@@ -697,6 +833,99 @@ extern "C" int mvo_tracker_step(mvo_ctx* ctx, const uint8_t* img, int w, int h, 
   int rc = mvo_batch_preload_frame(ctx, 0, p->step_entry, img, w, h, stride, channels);
   if (rc) return rc;
   return mvo_batch_track(ctx, p->step_entry, out);
+}
+
+// ---- output side ---------------------------------------------------------------------------------
+__global__ void trk_output_seed_kernel(mvo_ros_pose* __restrict__ ros, int* __restrict__ n_path, int slot, const float* __restrict__ lm, int n,
+                                       float* __restrict__ cloud, int* __restrict__ n_cloud, int map_cap, int* __restrict__ err) {
+  // the Initializer's hand-over (src/mono_vo.cpp:102-112): last_pose_ = identity, tracking valid, the map holds the seed landmarks
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float* out = cloud + (size_t)slot * map_cap * 3;
+  if (i < n && i < map_cap) { out[3 * i] = lm[3 * i + 2]; out[3 * i + 1] = -lm[3 * i]; out[3 * i + 2] = -lm[3 * i + 1]; }
+  if (i == 0) {
+    mvo_ros_pose r;
+    r.position[0] = r.position[1] = r.position[2] = 0.0;
+    r.orientation[0] = r.orientation[1] = r.orientation[2] = 0.0; r.orientation[3] = 1.0;
+    r.tracking_valid = 1; r.has_pose = 1;
+    ros[slot] = r;
+    n_path[slot] = 0;
+    if (n > map_cap) atomicOr(err, TRK_ERR_MAPCAP);
+    n_cloud[slot] = n < map_cap ? n : map_cap;
+  }
+}
+
+extern "C" int mvo_batch_enable_output(mvo_ctx* ctx, int map_capacity, int path_capacity) {
+  if (!ctx || !ctx->pipe || ctx->pipe->ring <= 0 || map_capacity < 1 || path_capacity < 1) return MVO_E_ARG;
+  int rc = trk_create(ctx);
+  if (rc) return rc;
+  TrackState* t = ctx->pipe->trk;
+  if (t->pending) { ctx->set_error("mvo_batch_enable_output: a step is in flight"); return MVO_E_ARG; }
+  MVO_HIP(hipStreamSynchronize(ctx->stream));
+  void* old[] = {t->d_cloud, t->d_n_cloud, t->d_path, t->d_n_path, t->d_ros};
+  for (void* q : old) if (q) (void)hipFree(q);
+  t->d_cloud = nullptr; t->d_n_cloud = nullptr; t->d_path = nullptr; t->d_n_path = nullptr; t->d_ros = nullptr;
+  t->out_on = false;
+  const size_t B = (size_t)ctx->B;
+  MVO_HIP(hipMalloc(&t->d_cloud, B * map_capacity * 3 * sizeof(float)));
+  MVO_HIP(hipMalloc(&t->d_n_cloud, B * sizeof(int)));
+  MVO_HIP(hipMalloc(&t->d_path, B * path_capacity * 7 * sizeof(double)));
+  MVO_HIP(hipMalloc(&t->d_n_path, B * sizeof(int)));
+  MVO_HIP(hipMalloc(&t->d_ros, B * sizeof(mvo_ros_pose)));
+  MVO_HIP(hipMemsetAsync(t->d_n_cloud, 0, B * sizeof(int), ctx->stream));
+  MVO_HIP(hipMemsetAsync(t->d_n_path, 0, B * sizeof(int), ctx->stream));
+  MVO_HIP(hipMemsetAsync(t->d_ros, 0, B * sizeof(mvo_ros_pose), ctx->stream));
+  t->map_cap = map_capacity; t->path_cap = path_capacity;
+  t->out_on = true;
+  return MVO_OK;
+}
+
+// called by mvo_batch_set_landmarks: the slot's seed landmarks (already resident at d_lm) open its map
+int trk_output_seed(mvo_ctx* ctx, int slot, const float* d_lm, int n) {
+  if (!ctx->pipe || !ctx->pipe->trk || !ctx->pipe->trk->out_on) return MVO_OK;
+  TrackState* t = ctx->pipe->trk;
+  hipLaunchKernelGGL(trk_output_seed_kernel, dim3((n + 255) / 256 + 1), dim3(256), 0, ctx->stream, t->d_ros, t->d_n_path, slot, d_lm, n, t->d_cloud,
+                     t->d_n_cloud, t->map_cap, t->d_err);
+  return MVO_OK;
+}
+
+static TrackState* trk_output_state(mvo_ctx* ctx) {
+  if (!ctx || !ctx->pipe || !ctx->pipe->trk || !ctx->pipe->trk->out_on) {
+    if (ctx) ctx->set_error("output side not enabled (mvo_batch_enable_output)");
+    return nullptr;
+  }
+  return ctx->pipe->trk;
+}
+
+extern "C" int mvo_batch_get_odometry(mvo_ctx* ctx, mvo_ros_pose* out) {
+  TrackState* t = trk_output_state(ctx);
+  if (!t || !out) return MVO_E_ARG;
+  MVO_HIP(hipStreamSynchronize(ctx->stream));
+  MVO_HIP(hipMemcpy(out, t->d_ros, (size_t)ctx->B * sizeof(mvo_ros_pose), hipMemcpyDeviceToHost));
+  return MVO_OK;
+}
+
+extern "C" int mvo_batch_get_path(mvo_ctx* ctx, int slot, double* poses, int cap, int* n) {
+  TrackState* t = trk_output_state(ctx);
+  if (!t || slot < 0 || slot >= ctx->B || !n || cap < 0 || (cap && !poses)) return MVO_E_ARG;
+  MVO_HIP(hipStreamSynchronize(ctx->stream));
+  int cnt = 0;
+  MVO_HIP(hipMemcpy(&cnt, t->d_n_path + slot, sizeof(int), hipMemcpyDeviceToHost));
+  *n = cnt;
+  if (cnt > cap) { ctx->set_error("mvo_batch_get_path: buffer too small"); return MVO_E_CAPACITY; }
+  if (cnt) MVO_HIP(hipMemcpy(poses, t->d_path + (size_t)slot * t->path_cap * 7, (size_t)cnt * 7 * sizeof(double), hipMemcpyDeviceToHost));
+  return MVO_OK;
+}
+
+extern "C" int mvo_batch_get_pointcloud(mvo_ctx* ctx, int slot, float* data, int cap, int* n) {
+  TrackState* t = trk_output_state(ctx);
+  if (!t || slot < 0 || slot >= ctx->B || !n || cap < 0 || (cap && !data)) return MVO_E_ARG;
+  MVO_HIP(hipStreamSynchronize(ctx->stream));
+  int cnt = 0;
+  MVO_HIP(hipMemcpy(&cnt, t->d_n_cloud + slot, sizeof(int), hipMemcpyDeviceToHost));
+  *n = cnt;
+  if (cnt > cap) { ctx->set_error("mvo_batch_get_pointcloud: buffer too small"); return MVO_E_CAPACITY; }
+  if (cnt) MVO_HIP(hipMemcpy(data, t->d_cloud + (size_t)slot * t->map_cap * 3, (size_t)cnt * 3 * sizeof(float), hipMemcpyDeviceToHost));
+  return MVO_OK;
 }
 
 // Tracker state of every slot: MVO_TRACK_* (and tracking_count_from_keyframe_).  Blocks until queued work has finished.

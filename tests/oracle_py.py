@@ -243,6 +243,24 @@ def epnp(obj, img, K):
     return r, t
 
 
+def solve_p3p4(obj, img, K, d=None):
+    obj, img = _f32(obj, 3), _f32(img, 2)
+    assert len(obj) == 4 and len(img) == 4
+    K = np.ascontiguousarray(K, np.float64).reshape(9)
+    d = np.zeros(5) if d is None else np.ascontiguousarray(d, np.float64).reshape(5)
+    r = np.zeros(3); t = np.zeros(3)
+    n = lib().orc_solve_p3p4(_p(obj), _p(img), _p(K), _p(d), _p(r), _p(t))
+    return n, r, t
+
+
+def solve_deg4(a, b, c, d, e):
+    roots = np.zeros(4)
+    f = lib().orc_solve_deg4
+    f.argtypes = [C.c_double] * 5 + [C.c_void_p]
+    n = f(a, b, c, d, e, _p(roots))
+    return roots[:n].copy()
+
+
 def solve_pnp_ransac(obj, img, K, d=None, iters=100, reproj=8.0, conf=0.99):
     obj, img = _f32(obj, 3), _f32(img, 2)
     K = np.ascontiguousarray(K, np.float64).reshape(9)

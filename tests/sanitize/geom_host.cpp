@@ -44,6 +44,12 @@ void host_epnp5(const float* obj, const float* img, const double* K, double* rve
   gm_epnp5(obj, img, cam, rvec, tvec, ws);
 }
 
+// solvePnPRansac's four-point branch (P3P + fourth point); returns the number of P3P solutions
+int host_p3p4(const float* obj, const float* img, const double* K, const double* d, double* rvec, double* tvec) {
+  CamK cam = make_camk(K, d);
+  return gm_p3p4(obj, img, cam, rvec, tvec);
+}
+
 int host_e5(const float* p1, const float* p2, const double* K, double* E90) {
   ModelParams P{};
   P.cam = make_camk(K, nullptr);

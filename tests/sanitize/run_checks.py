@@ -51,6 +51,14 @@ for seed in range(12):
     rt = np.ascontiguousarray(np.stack([r, t], 1).reshape(6))
     e = L.host_pnp_err(p(rt), p(K), p(X[0]), p(m[0]))
     assert np.isfinite(e) and e >= 0
+    # --- P3P on four correspondences (solvePnPRansac's n == 4 branch), without and with plumb-bob distortion
+    for dist in (None, np.array([-0.28, 0.07, 2e-4, -1e-4, 0.01])):
+        X4, m4 = np.ascontiguousarray(X[:4]), np.ascontiguousarray(m[:4])
+        d5 = np.zeros(5) if dist is None else np.ascontiguousarray(dist)
+        r4 = np.zeros(3); t4 = np.zeros(3)
+        n4 = L.host_p3p4(p(X4), p(m4), p(K), p(d5), p(r4), p(t4))
+        on, orv4, otv4 = O.solve_p3p4(X4, m4, sc["K"], dist)
+        assert n4 == on and np.array_equal(r4, orv4) and np.array_equal(t4, otv4), ("P3P", seed, n4, on, r4, orv4)
     # --- 5-point essential matrix
     E = np.zeros(90)
     a, b = np.ascontiguousarray(sc["p1"][idx]), np.ascontiguousarray(sc["p2"][idx])

@@ -77,6 +77,28 @@ def test_pnp_ransac(ctx720, P, planar):
     assert np.abs(O.rodrigues(r) - Rgt).max() < 2e-3 and np.abs(t - sc["t"]).max() < 5e-2
 
 
+def test_pnp_four_point_branch_is_p3p(ctx720):
+    """n == 4 (src/tracker.cpp:309 with min_tracked_points lowered): solvePnP(SOLVEPNP_P3P) on all four, inliers 0..3, no
+    refinement - the device restatement against the oracle's, with and without plumb-bob distortion; fewer than four is
+    refused like OpenCV's CV_Assert(npoints >= 4)."""
+    from ros2_mono_vo_amd import _lib
+    K = synth.default_K(1280, 720)
+    for d in (None, np.array([-0.3, 0.09, 0.001, -0.0007, -0.01])):
+        rng = np.random.default_rng(3)
+        for _ in range(25):
+            X = rng.uniform(-2, 2, (4, 3)) + np.array([0, 0, 6.0])
+            Xc = X @ O.rodrigues(rng.normal(0, 0.2, 3)).T + rng.normal(0, 0.5, 3)
+            uv = Xc[:, :2] / Xc[:, 2:3] * np.array([K[0, 0], K[1, 1]]) + np.array([K[0, 2], K[1, 2]])
+            ok, r, t, idx = ctx720.solve_pnp_ransac(X, uv, K, d)
+            rc, orv, otv, oidx, _ = O.solve_pnp_ransac(X, uv, K, d)
+            assert ok == (rc == 1)
+            if ok:
+                assert np.array_equal(idx, [0, 1, 2, 3]) and np.array_equal(oidx, [0, 1, 2, 3])
+                assert np.abs(r - orv).max() <= 1e-9 * max(1.0, np.abs(orv).max()) and np.abs(t - otv).max() <= 1e-9 * max(1.0, np.abs(otv).max())
+    with pytest.raises(_lib.MvoError):
+        ctx720.solve_pnp_ransac(X[:3], uv[:3], K)
+
+
 @pytest.mark.parametrize("waves", [1, 4])
 def test_pnp_refine_block_sizes(waves, monkeypatch):
     """The LM refine runs one wavefront per stream when many streams are resident and four when few are (latency);

@@ -213,3 +213,68 @@ def test_single_stream_tracker_step_matches_the_batch_form():
                     run.append(key(ctx.batch_track(k)[0]))
             outs.append(run)
     assert outs[0] == outs[1] and any(o[9] & _lib.STEP_KEYFRAME for o in outs[0])
+
+
+def test_output_side_on_the_device_matches_the_node_bookkeeping():
+    """SURVEY 8(f) rank 4 on the HIP path: with mvo_batch_enable_output every step ends with MonoVO::image_callback's pose
+    bookkeeping per slot (src/mono_vo.cpp:117-152) - last_pose_ in REP-103 (src/utils.cpp:85-129), the path, and the Map as
+    PointCloud2 payload (src/utils.cpp:190-243) in landmark-id order.  Checked against the host restatement (ros_io.py) fed
+    with the reference tracker's poses and Map (tests/track_ref.py over the oracle): seed cloud bytes identical, later landmarks within float32 rounding, poses <= 1e-9."""
+    from ros2_mono_vo_amd import ros_io
+    import oracle_py as O
+    N, NF = 26, 1000
+    K = synth.default_K(TS.W, TS.H)
+    kinds = ("lateral", "fast", "cut")
+    data = [TS.stream(kind, N) for kind in kinds]
+    B = len(data)
+    with Context(max_width=TS.W, max_height=TS.H, batch=B, nfeatures=NF, max_points=4096, ring_frames=N) as ctx:
+        ctx.batch_set_intrinsics(K)
+        ctx.batch_enable_output(map_capacity=32768, path_capacity=64)
+        for s in range(B):
+            for f in range(N):
+                ctx.batch_preload_frame(s, f, data[s][0][f])
+        ctx.batch_seed(0)
+        refs, paths, valid = [], [ros_io.PathAccumulator() for _ in range(B)], [True] * B
+        last = [(np.eye(3), np.zeros(3))] * B
+        for s, (fr, d0) in enumerate(data):
+            r = TrackRef(K, NF)
+            n, xy, lm = r.seed(fr[0], TS.depth_landmarks(K, d0))
+            ctx.batch_set_landmarks(s, lm)
+            refs.append(r)
+        for s in range(B):   # the hand-over state: identity pose, the seed landmarks in the cloud, an empty path
+            assert np.array_equal(ctx.batch_get_pointcloud(s).tobytes(), ros_io.pointcloud2(refs[s].map.get_landmark_points(), 0)["data"])
+            assert len(ctx.batch_get_path(s)) == 0
+        grew = [False] * B
+        for k in range(1, N):
+            out = ctx.batch_track(k)
+            odo = ctx.batch_get_odometry()
+            for s, r in enumerate(refs):
+                n_before = len(r.map.landmarks)
+                e = r.step(data[s][0][k])
+                check(out[s], e, (k, kinds[s]))
+                grew[s] |= len(r.map.landmarks) > n_before
+                if e["state"] == _lib.TRACK_LOST:
+                    valid[s] = False
+                elif e["flags"] & _lib.STEP_POSE:
+                    R = O.rodrigues(e["rvec"])
+                    last[s] = (R.T, -R.T @ e["tvec"])
+                    valid[s] = True
+                if valid[s]:
+                    paths[s].push(last[s][0], last[s][1], k)
+                pos, quat = ros_io.pose_cv_to_ros(*last[s])
+                assert bool(odo[s].tracking_valid) == valid[s] and odo[s].has_pose == 1
+                assert np.abs(np.array(odo[s].position) - pos).max() < 1e-9 and np.abs(np.array(odo[s].orientation) - quat).max() < 1e-9
+        for s, r in enumerate(refs):
+            cloud = ctx.batch_get_pointcloud(s)
+            want = ros_io.pointcloud2(r.map.get_landmark_points(), 0)
+            # new landmarks are triangulated with the frame's PnP pose, which agrees with the oracle's to ~1e-9, not bit for
+            # bit: same landmarks in the same order, coordinates within float32 rounding of each other
+            wantp = np.frombuffer(want["data"], "<f4").reshape(-1, 3)
+            assert cloud.dtype == np.float32 and len(cloud) == want["width"], (kinds[s], len(cloud), want["width"])
+            assert np.abs(cloud - wantp).max() <= 2e-6 * max(1.0, np.abs(wantp).max()), kinds[s]
+            path = ctx.batch_get_path(s)
+            assert len(path) == len(paths[s].poses)
+            for a, b in zip(path, paths[s].poses):
+                assert np.abs(a[:3] - b["position"]).max() < 1e-9 and np.abs(a[3:] - b["orientation"]).max() < 1e-9
+        # every seed observation has a landmark, so a slot's FIRST key-frame adds none; the fast mover's later ones do
+        assert grew[1] and not valid[2] and len(paths[2].poses) < N - 1 == len(paths[1].poses)   # ... and the cut stream went LOST

@@ -291,3 +291,50 @@ def test_pnp_distortion_planted_pose():
     # without the coefficients the same data has far fewer inliers at the 8 px gate or a worse pose
     rc0, rv0, tv0, idx0, _ = O.solve_pnp_ransac(X, img, K)
     assert rc0 != 1 or len(idx0) < len(idx) or np.abs(tv0 - t).max() > 3 * np.abs(tv - t).max()
+
+
+def _p3p_problem(rng, K, d=None):
+    """four object points in front of the camera, their exact (optionally plumb-bob distorted) projections, the planted pose"""
+    while True:   # inside the image: the five fixed-point iterations of undistortPoints do not converge far outside it
+        X = rng.uniform(-2, 2, (4, 3)) + np.array([0, 0, 6.0])
+        rv, t = rng.normal(0, 0.2, 3), rng.normal(0, 0.5, 3)
+        Xc = X @ O.rodrigues(rv).T + t
+        x, y = Xc[:, 0] / Xc[:, 2], Xc[:, 1] / Xc[:, 2]
+        if np.abs(x * K[0, 0]).max() < K[0, 2] and np.abs(y * K[1, 1]).max() < K[1, 2]:
+            break
+    if d is not None:
+        k1, k2, p1, p2, k3 = d
+        r2 = x * x + y * y
+        cd = 1 + k1 * r2 + k2 * r2 ** 2 + k3 * r2 ** 3
+        x, y = x * cd + 2 * p1 * x * y + p2 * (r2 + 2 * x * x), y * cd + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+    return X, np.stack([x * K[0, 0] + K[0, 2], y * K[1, 1] + K[1, 2]], 1), rv, t
+
+
+def test_quartic_closed_form_finds_planted_roots():
+    """polynom_solver.cpp solve_deg4 (the resolvent-cubic closed form P3P relies on): four planted real roots come back."""
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        r = np.sort(rng.uniform(-3, 3, 4))
+        if np.diff(r).min() < 0.05:
+            continue
+        got = np.sort(O.solve_deg4(*(2.5 * np.poly(r))))
+        assert len(got) == 4 and np.abs(got - r).max() < 1e-6
+    assert len(O.solve_deg4(1, 0, 3, 0, 2)) == 0            # (x^2 + 1)(x^2 + 2): no real root
+    assert np.allclose(np.sort(O.solve_deg4(0, 1, -6, 11, -6)), [1, 2, 3])   # a == 0 falls through to the cubic
+
+
+def test_p3p_four_point_branch_recovers_planted_pose():
+    """solvePnPRansac with exactly four correspondences = solvePnP(SOLVEPNP_P3P) on all four (model_points == npoints): no
+    RANSAC, every point an inlier, the pose is the P3P solution the fourth point selects.  Planted geometry, with and
+    without distortion; the inputs are rounded to float32 like the reference's Point2f / Point3f."""
+    K = synth.default_K(1280, 720)
+    for d in (None, np.array([-0.3, 0.09, 0.001, -0.0007, -0.01])):
+        rng = np.random.default_rng(11)
+        good = 0
+        for _ in range(100):
+            X, uv, rv, t = _p3p_problem(rng, K, d)
+            rc, r, tv, idx, _ = O.solve_pnp_ransac(X, uv, K, d)
+            n, r2, t2 = O.solve_p3p4(X, uv, K, d)
+            assert rc == 1 and n >= 1 and np.array_equal(idx, [0, 1, 2, 3]) and np.array_equal(r, r2) and np.array_equal(tv, t2)
+            good += np.abs(O.rodrigues(r) - O.rodrigues(rv)).max() < 2e-3 and np.abs(tv - t).max() < 2e-2
+        assert good >= 97   # a few configurations are ill-conditioned at float32 input precision
