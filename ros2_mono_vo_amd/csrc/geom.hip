@@ -70,8 +70,17 @@ __global__ __launch_bounds__(64 * NW, RS_WAVES_PER_EU) void ransac_kernel(Ransac
   // per-lane workspace stride: == 1 (mod 32) doubles, so lane-uniform 8-byte accesses of 16 lanes fall into distinct banks
   constexpr int WSS = M::WS > 0 ? ((M::WS + 30) / 32) * 32 + 1 : 1;
   __shared__ double s_ws[(M::WS > 0 ? CH0 * NW : 1) * WSS];
-  __shared__ int s_att[RS_CH][M::MP];
-  __shared__ int s_idx[RS_CH][M::MP];
+  // Candidates of a refill / queue of the passing ones still to be solved.  M::OVERDRAW: a refill draws and checks one
+  // candidate per THREAD (RS_TT of them) instead of one per solver lane, the passing ones queue up in draw order and a
+  // round solves the first RS_CH of the queue: when checkSubset rejects most samples (findHomography on a scene a
+  // homography explains only partly: ~70 % rejected) the solver lanes stay full instead of a round solving what
+  // happened to pass of its own RS_CH draws.  The candidate ORDER - all that OpenCV's sequential loop observes - is
+  // unchanged: passing candidates are consumed first in, first out.
+  constexpr int RS_DR = M::OVERDRAW ? RS_TT : RS_CH;
+  constexpr int RS_Q = M::OVERDRAW ? RS_CH + RS_DR : RS_CH;
+  __shared__ int s_att[RS_DR][M::MP];
+  __shared__ int s_idx[RS_Q][M::MP];
+  __shared__ int s_qn;   // passing candidates queued
   __shared__ double s_models[RS_CH][M::MAXM][M::MS];
   __shared__ int s_nmodels[RS_CH];
   __shared__ int s_cnt[RS_CH][M::MAXM];
@@ -124,6 +133,7 @@ __global__ __launch_bounds__(64 * NW, RS_WAVES_PER_EU) void ransac_kernel(Ransac
   if (tid == 0) {
     s_rng = 0xFFFFFFFFFFFFFFFFULL;
     s_ctl[1] = 0; s_ctl[2] = 0; s_ctl[3] = 0; s_ctl[4] = A.max_iters > 1 ? A.max_iters : 1; s_ctl[5] = 0; s_ctl[6] = 0; s_ctl[7] = 0;
+    s_qn = 0;
     if (lmeds) { int ni = gl_ransac_update_num_iters(A.conf, 0.45, M::MP, 1000); s_ctl[4] = ni > 3 ? ni : 3; }
     s_minmed = DBL_MAX;
   }
@@ -157,64 +167,69 @@ __global__ __launch_bounds__(64 * NW, RS_WAVES_PER_EU) void ransac_kernel(Ransac
 #endif
   for (;;) {
     const int ch = NW > 1 ? RS_CH : ((M::WS > 0 && s_ctl[4] - s_ctl[3] <= CH0) || (M::WS > 0 && s_ctl[3] == 0) ? CH0 : RS_CH);  // uniform
-    const int cpw = ch / NW;                                  // candidates per wave
-    const int cand = lane < cpw ? wave * cpw + lane : -1;     // this thread's candidate / hypothesis of the round
-    // ---- 1. candidate samples, OpenCV's getSubset draw order (sequential RNG stream, lane 0) ----------
-    if (tid == 0) {
-      GlRng rng(s_rng);
-      // never draw (much) more than can still be consumed: iterations left, with head-room for checkSubset rejects
-      for (int a = 0; a < ch; a++) {
-        for (int i = 0; i < M::MP; ++i) {
-          int idx_i;
-          for (;;) {
-            idx_i = rng.uniform(0, count);
-            bool dup = false;
-            for (int k = 0; k < i; k++) dup |= (s_att[a][k] == idx_i);
-            if (!dup) break;
-          }
-          s_att[a][i] = idx_i;
-        }
-      }
-      s_rng = rng.state;
-    }
-    __syncthreads();
-    RS_TICK(0)
-    // ---- 2. checkSubset in parallel (one candidate per lane) + ordered compaction over the 4 waves -------
+    const int cpw = ch / NW;                                  // hypotheses per wave
+    const int cand = lane < cpw ? wave * cpw + lane : -1;     // this thread's hypothesis of the round
+    const int want = min(ch, s_ctl[4] - s_ctl[3]);            // hypotheses the round can consume (uniform)
     float ms1[M::MP * M::PT1], ms2[M::MP * M::PT2];
-    bool pass = false;
-    if (cand >= 0) {
-      for (int i = 0; i < M::MP; i++) {
-        int id = s_att[cand][i];
-        for (int k = 0; k < M::PT1; k++) ms1[i * M::PT1 + k] = m1[(size_t)id * M::PT1 + k];
-        for (int k = 0; k < M::PT2; k++) ms2[i * M::PT2 + k] = m2[(size_t)id * M::PT2 + k];
-      }
-      pass = M::check_subset(ms1, ms2);
-    }
-    const unsigned long long bm = __ballot(pass);
-    if (lane == 0) { s_wpass[wave] = __popcll(bm); s_wmask[wave] = bm; }
-    __syncthreads();
-    int pos = __popcll(bm & ((1ull << lane) - 1));
-    for (int w = 0; w < wave; w++) pos += s_wpass[w];
-    if (pass)
-      for (int i = 0; i < M::MP; i++) s_idx[pos][i] = s_att[cand][i];
-    if (tid == 0) {
-      // OpenCV gives up on an iteration after 10000 consecutive failing attempts: walk the pass bits in order
-      int np = 0, run = s_ctl[5];
-      bool abort_ = false;
-      const int CPW = cpw;  // candidates held by a wave's ballot
-      for (int w = 0; w < NW; w++) {
-        unsigned long long m = s_wmask[w];
-        np += __popcll(m);
-        if (m == 0) { run += CPW; abort_ |= run >= 10000; }
-        else {
-          int lead = __ffsll((long long)m) - 1;
-          abort_ |= (run + lead) >= 10000;
-          run = __clzll(m) - (64 - CPW);  // failing candidates after the last passing one
+    if (s_qn < want) {   // uniform
+      // ---- 1. candidate samples, OpenCV's getSubset draw order (sequential RNG stream, lane 0) ----------
+      const int ndraw = M::OVERDRAW ? RS_DR : ch;
+      const int q0 = s_qn;
+      if (tid == 0) {
+        GlRng rng(s_rng);
+        for (int a = 0; a < ndraw; a++) {
+          for (int i = 0; i < M::MP; ++i) {
+            int idx_i;
+            for (;;) {
+              idx_i = rng.uniform(0, count);
+              bool dup = false;
+              for (int k = 0; k < i; k++) dup |= (s_att[a][k] == idx_i);
+              if (!dup) break;
+            }
+            s_att[a][i] = idx_i;
+          }
         }
+        s_rng = rng.state;
       }
-      s_ctl[0] = np;
-      s_ctl[5] = run;
-      if (abort_) s_ctl[1] = 1;
+      __syncthreads();
+      RS_TICK(0)
+      // ---- 2. checkSubset in parallel (one candidate per lane / per thread) + ordered compaction over the waves -------
+      const int dcand = M::OVERDRAW ? tid : cand;   // candidate d of the refill belongs to wave d / CPW, lane d % CPW
+      bool pass = false;
+      if (dcand >= 0) {
+        for (int i = 0; i < M::MP; i++) {
+          int id = s_att[dcand][i];
+          for (int k = 0; k < M::PT1; k++) ms1[i * M::PT1 + k] = m1[(size_t)id * M::PT1 + k];
+          for (int k = 0; k < M::PT2; k++) ms2[i * M::PT2 + k] = m2[(size_t)id * M::PT2 + k];
+        }
+        pass = M::check_subset(ms1, ms2);
+      }
+      const unsigned long long bm = __ballot(pass);
+      if (lane == 0) { s_wpass[wave] = __popcll(bm); s_wmask[wave] = bm; }
+      __syncthreads();
+      int pos = q0 + __popcll(bm & ((1ull << lane) - 1));
+      for (int w = 0; w < wave; w++) pos += s_wpass[w];
+      if (pass)
+        for (int i = 0; i < M::MP; i++) s_idx[pos][i] = s_att[dcand][i];
+      if (tid == 0) {
+        // OpenCV gives up on an iteration after 10000 consecutive failing attempts: walk the pass bits in order
+        int np = 0, run = s_ctl[5];
+        bool abort_ = false;
+        const int CPW = M::OVERDRAW ? 64 : cpw;  // candidates held by a wave's ballot
+        for (int w = 0; w < NW; w++) {
+          unsigned long long m = s_wmask[w];
+          np += __popcll(m);
+          if (m == 0) { run += CPW; abort_ |= run >= 10000; }
+          else {
+            int lead = __ffsll((long long)m) - 1;
+            abort_ |= (run + lead) >= 10000;
+            run = __clzll(m) - (64 - CPW);  // failing candidates after the last passing one
+          }
+        }
+        s_qn = q0 + np;
+        s_ctl[5] = run;
+        if (abort_) s_ctl[1] = 1;
+      }
     }
     if (tid < RS_CH) {
       s_nmodels[tid] = 0;
@@ -222,10 +237,10 @@ __global__ __launch_bounds__(64 * NW, RS_WAVES_PER_EU) void ransac_kernel(Ransac
     }
     __syncthreads();
     if (s_ctl[1]) break;
-    const int npass = s_ctl[0];
+    const int npass = s_qn;
     RS_TICK(1)
     // ---- 3. minimal solver, one hypothesis per lane; only as many as can still be consumed ---------------
-    const int nsolve = min(npass, s_ctl[4] - s_ctl[3]);
+    const int nsolve = min(npass, want);
     int nm = 0;
     if (cand >= 0 && cand < nsolve) {
       for (int i = 0; i < M::MP; i++) {
@@ -306,6 +321,17 @@ __global__ __launch_bounds__(64 * NW, RS_WAVES_PER_EU) void ransac_kernel(Ransac
     __syncthreads();
     RS_TICK(4)
     if (s_ctl[1]) break;
+    if (M::OVERDRAW) {   // the candidates solved leave the queue, the others move up (read, barrier, write: ranges overlap)
+      const int left = npass - nsolve;
+      int keep[RS_Q / RS_TT + 1][M::MP];
+      for (int e = tid, j = 0; e < left; e += RS_TT, j++)
+        for (int i = 0; i < M::MP; i++) keep[j][i] = s_idx[nsolve + e][i];
+      __syncthreads();
+      for (int e = tid, j = 0; e < left; e += RS_TT, j++)
+        for (int i = 0; i < M::MP; i++) s_idx[e][i] = keep[j][i];
+      if (tid == 0) s_qn = left;
+      __syncthreads();
+    } else if (tid == 0) s_qn = 0;   // a round without over-draw consumes what it drew (or the loop has ended)
   }
   // ---- consensus mask of the winning model ---------------------------------------------------------------------
   if (lmeds) {
@@ -901,7 +927,7 @@ int geom_ransac_h(mvo_ctx* ctx, int nslots, const float* p1, const float* p2, co
                   u8* mask, double* model, int* result, hipStream_t st) {
   if (!st) st = ctx->stream;
   ModelParams P{};
-  launch_ransac<HModel, 4>(ctx, st, nslots, p1, p2, ctx->maxpts * 2, ctx->maxpts * 2, d_n, thr, conf, max_iters, P, mask, ctx->maxpts, model, result);
+  launch_ransac<HModel, RS_H_NW>(ctx, st, nslots, p1, p2, ctx->maxpts * 2, ctx->maxpts * 2, d_n, thr, conf, max_iters, P, mask, ctx->maxpts, model, result);
   return MVO_OK;
 }
 int geom_ransac_f(mvo_ctx* ctx, int nslots, const float* p1, const float* p2, const int* d_n, double thr, int max_iters, double conf,

@@ -27,15 +27,26 @@ struct ModelParams { CamK cam; };
 // ---------------------------------------------------------------------------------------------------
 // Homography, 4 points (HomographyEstimatorCallback)
 // ---------------------------------------------------------------------------------------------------
+// Homography rounds: RS_H_NW wavefronts per stream, RS_H_CH hypotheses each (64 per round, 106 KB of LDS workspaces)
+#ifndef RS_H_NW
+#define RS_H_NW 4
+#endif
+#ifndef RS_H_CH
+#define RS_H_CH (64 / RS_H_NW)
+#endif
+#ifndef RS_H_OVERDRAW
+#define RS_H_OVERDRAW 1
+#endif
 struct HModel {
   static constexpr int MP = 4, MAXM = 1, MS = 9, PT1 = 2, PT2 = 2;
   // 16 hypotheses per round, every round in LDS (16 x 193 doubles = 25 KB): a 64-wide round with 48 workspaces in
   // private memory took 2.85 ms against 0.8 ms for an LDS round, i.e. more per hypothesis; wider LDS rounds (24, 32)
   // made the workgroup wait for LDS beside the image kernels
-  static constexpr int CH = 16, WS = 81 + 9 + 81;  // LtL, W, V
+  static constexpr int CH = RS_H_CH, WS = 81 + 9 + 81;  // LtL, W, V
   static constexpr bool WIDE = false;
   static constexpr int LMEDS_BELOW = 0;
   static constexpr int MP_ALT = 0;   // no second sample size
+  static constexpr bool OVERDRAW = RS_H_OVERDRAW != 0;   // checkSubset rejects most samples of a non-planar scene: refill the queue with one candidate per thread
 
   __device__ static bool check_subset(const float* ms1, const float* ms2) {
     if (gl_have_collinear(ms1, 4) || gl_have_collinear(ms2, 4)) return false;
@@ -135,6 +146,7 @@ struct FModel {
   static constexpr bool WIDE = true;
   static constexpr int LMEDS_BELOW = 15;  // findFundamentalMat: FM_RANSAC with fewer than 15 points runs LMedS (fundam.cpp)
   static constexpr int MP_ALT = 0;   // no second sample size
+  static constexpr bool OVERDRAW = false;
 
   __device__ static bool check_subset(const float* ms1, const float* ms2) {
     return !gl_have_collinear(ms1, 7) && !gl_have_collinear(ms2, 7);
@@ -1098,6 +1110,7 @@ struct PnPModel {
   static constexpr bool WIDE = false;
   static constexpr int LMEDS_BELOW = 0;
   static constexpr int MP_ALT = 4;   // four correspondences: P3P on all of them instead of RANSAC
+  static constexpr bool OVERDRAW = false;
   __device__ static int solve_alt(const ModelParams& P, const float* ms1, const float* ms2, double* model) {
     double rvec[3], tvec[3];
     if (gm_p3p4(ms1, ms2, P.cam, rvec, tvec) == 0) return 0;
@@ -1353,6 +1366,7 @@ struct EModel {
   static constexpr bool WIDE = true;
   static constexpr int LMEDS_BELOW = 0;
   static constexpr int MP_ALT = 0;   // no second sample size
+  static constexpr bool OVERDRAW = false;
   __device__ static bool check_subset(const float*, const float*) { return true; }
   __device__ static int solve(const ModelParams& P, const float* ms1, const float* ms2, double* models, double*) {
     double q1[10], q2[10];

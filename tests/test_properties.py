@@ -8,7 +8,7 @@ from hypothesis import HealthCheck, given, settings, strategies as st
 import oracle_py as O
 from ros2_mono_vo_amd import synth
 
-SET = dict(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+SET = dict(max_examples=25, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 
 
 def hamming(a, b):
@@ -48,7 +48,7 @@ def test_matcher_ties_and_ratio_oracle(seed, nq, nt, dup, ratio):
 
 
 @given(seed=st.integers(0, 2**31))
-@settings(max_examples=6, deadline=None)
+@settings(max_examples=6, deadline=None, derandomize=True)
 def test_lk_zero_motion_is_zero_flow_oracle(seed):
     img = synth.gen_stream(160, 120, 0x5EED0900 + seed % 1000, 1)[0]
     rng = np.random.default_rng(seed)
@@ -74,7 +74,9 @@ def check_ransac_subset(ok, mask, model, p1, p2, thr, kind):
         b = np.c_[p2, np.ones(len(p2))] @ model                 # F^T x2
         d2 = (np.c_[p2, np.ones(len(p2))] * a).sum(1)
         err = np.maximum(d2 ** 2 / (a[:, 0] ** 2 + a[:, 1] ** 2), d2 ** 2 / (b[:, 0] ** 2 + b[:, 1] ** 2))
-    inside = err <= thr * thr * (1 + 1e-6) + 1e-9
+    # OpenCV scores in float32 (computeError works on the float copy of the model): at pixel magnitudes of ~1e3 a squared
+    # error next to the gate moves by ~1e-4 between float and this double evaluation (found: 1.000062 accepted at thr 1)
+    inside = err <= thr * thr * (1 + 1e-3) + 1e-6
     assert not np.any((mask != 0) & ~inside)                     # mask is a subset of the threshold set
     assert (mask != 0).sum() >= (4 if kind == "H" else 7)
 
@@ -107,7 +109,7 @@ def test_matcher_ties_and_ratio_hip(ctx480, seed, nq, nt, dup, ratio):
 
 @pytest.mark.gpu
 @given(seed=st.integers(0, 2**31))
-@settings(max_examples=6, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@settings(max_examples=6, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
 def test_lk_zero_motion_is_zero_flow_hip(ctx480, seed):
     img = synth.gen_stream(160, 120, 0x5EED0900 + seed % 1000, 1)[0]
     rng = np.random.default_rng(seed)
