@@ -36,7 +36,9 @@ struct RansacArgs {
   u8* mask;
   int mask_stride;
   double* model;  // [B][16]
-  int* result;    // [B][8]: ok, n_inliers, iters_run, niters_final, models_scored
+  int* result;    // [B][8]: ok, n_inliers, iters_run, niters_final, models_scored, [5] (idx != null) entries of the index list
+  int* idx;       // [B][idx_stride] ordered list of the consensus set (solvePnPRansac's `inliers`), or null
+  int idx_stride;
 };
 
 // Candidate samples per round = M::CH (16 for H / F / PnP): their solvers keep the dense matrices in a per-lane LDS
@@ -58,6 +60,36 @@ struct RansacArgs {
 // times as wide at the same latency.  The easy case (consensus after a handful of iterations) costs the same as with one
 // wave; a hard stream - findHomography under true parallax needs hundreds to 2000 iterations - finishes NW times sooner,
 // and the batch launch lasts as long as its hardest stream.  Candidate c of a round belongs to wave c / CPW, lane c % CPW.
+// The consensus mask as solvePnPRansac's ordered inlier list, by the workgroup that wrote the mask (a separate launch for
+// this cost 0.3 ms of stream time per step beside other contexts' kernels).
+template <int RS_TT>
+__device__ inline void ransac_mask_to_indices(const u8* mask, int count, int* idx, int* s_wave /* [RS_TT / 64] */, int* s_base, int* result) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NWV = RS_TT / 64;
+  __syncthreads();   // the mask is complete
+  if (tid == 0) *s_base = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < count; i0 += RS_TT) {
+    const int i = i0 + tid;
+    const bool keep = i < count && mask[i];
+    const unsigned long long m = __ballot(keep);
+    const int pre = __popcll(m & ((1ull << lane) - 1));
+    if (lane == 0) s_wave[wave] = __popcll(m);
+    __syncthreads();
+    int off = *s_base;
+    for (int w = 0; w < wave; w++) off += s_wave[w];
+    if (keep) idx[off + pre] = i;
+    __syncthreads();
+    if (tid == 0) {
+      int t = 0;
+      for (int w = 0; w < NWV; w++) t += s_wave[w];
+      *s_base += t;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) result[5] = *s_base;
+}
+
 template <class M, int NW>
 __global__ __launch_bounds__(64 * NW, RS_WAVES_PER_EU) void ransac_kernel(RansacArgs A) {
   constexpr int RS_TT = 64 * NW;
@@ -81,6 +113,8 @@ __global__ __launch_bounds__(64 * NW, RS_WAVES_PER_EU) void ransac_kernel(Ransac
   __shared__ int s_att[RS_DR][M::MP];
   __shared__ int s_idx[RS_Q][M::MP];
   __shared__ int s_qn;   // passing candidates queued
+  __shared__ int s_lwave[NW], s_lbase;   // ordered inlier list (A.idx)
+  int* const out_idx = A.idx ? A.idx + (size_t)blockIdx.x * A.idx_stride : nullptr;
   __shared__ double s_models[RS_CH][M::MAXM][M::MS];
   __shared__ int s_nmodels[RS_CH];
   __shared__ int s_cnt[RS_CH][M::MAXM];
@@ -120,11 +154,12 @@ __global__ __launch_bounds__(64 * NW, RS_WAVES_PER_EU) void ransac_kernel(Ransac
     const int ok = s_ctl[6];
     for (int i = tid; i < count; i += RS_TT) mask[i] = ok ? 1 : 0;
     if (tid == 0) { result[0] = ok; result[1] = ok ? count : 0; result[2] = 1; result[3] = 1; result[4] = 1; }
+    if (out_idx) ransac_mask_to_indices<RS_TT>(mask, count, out_idx, s_lwave, &s_lbase, result);
     return;
   }
   if (count < M::MP) {
     for (int i = tid; i < count; i += RS_TT) mask[i] = 0;
-    if (tid == 0) { result[0] = 0; result[1] = 0; result[2] = 0; result[3] = 0; result[4] = 0; }
+    if (tid == 0) { result[0] = 0; result[1] = 0; result[2] = 0; result[3] = 0; result[4] = 0; if (out_idx) result[5] = 0; }
     return;
   }
   // LMeDSPointSetRegistrator instead of RANSAC (findFundamentalMat below 15 points): fixed iteration count from the
@@ -155,6 +190,7 @@ __global__ __launch_bounds__(64 * NW, RS_WAVES_PER_EU) void ransac_kernel(Ransac
     int ok = s_ctl[6];
     for (int i = tid; i < count; i += RS_TT) mask[i] = ok ? 1 : 0;
     if (tid == 0) { result[0] = ok; result[1] = ok ? count : 0; result[2] = 1; result[3] = 1; result[4] = 1; }
+    if (out_idx) ransac_mask_to_indices<RS_TT>(mask, count, out_idx, s_lwave, &s_lbase, result);
     return;
   }
 
@@ -372,6 +408,7 @@ __global__ __launch_bounds__(64 * NW, RS_WAVES_PER_EU) void ransac_kernel(Ransac
     for (int i = tid; i < count; i += RS_TT) mask[i] = 0;
   }
   if (tid == 0) { result[0] = maxGood > 0; result[1] = maxGood; result[2] = s_ctl[3]; result[3] = s_ctl[4]; result[4] = s_ctl[7]; }
+  if (out_idx) ransac_mask_to_indices<RS_TT>(mask, count, out_idx, s_lwave, &s_lbase, result);
 #ifdef RS_TIMING
   RS_TICK(5)
   if (tid == 0 && slot < 4)
@@ -383,35 +420,6 @@ __global__ __launch_bounds__(64 * NW, RS_WAVES_PER_EU) void ransac_kernel(Ransac
 // ---------------------------------------------------------------------------------------------------
 // PnP: consensus set -> ordered inlier list; then cvFindExtrinsicCameraParams2 (DLT / planar init + LM)
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void mask_to_indices_kernel(const u8* __restrict__ mask, int mask_stride, const int* __restrict__ n_,
-                                                               int* __restrict__ idx, int idx_stride, int* __restrict__ result) {
-  __shared__ int s_wave[16];
-  __shared__ int s_base;
-  const int slot = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n = min(max(n_[slot], 0), mask_stride);
-  if (threadIdx.x == 0) s_base = 0;
-  __syncthreads();
-  for (int i0 = 0; i0 < n; i0 += 1024) {
-    int i = i0 + threadIdx.x;
-    bool keep = i < n && mask[(size_t)slot * mask_stride + i];
-    unsigned long long m = __ballot(keep);
-    int pre = __popcll(m & ((1ull << lane) - 1));
-    if (lane == 0) s_wave[wave] = __popcll(m);
-    __syncthreads();
-    int off = s_base;
-    for (int w = 0; w < wave; w++) off += s_wave[w];
-    if (keep) idx[(size_t)slot * idx_stride + off + pre] = i;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int t = 0;
-      for (int w = 0; w < 16; w++) t += s_wave[w];
-      s_base += t;
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) result[(size_t)slot * 8 + 5] = s_base;
-}
-
 // Block size of the refine.  Throughput mode (many streams resident) runs one wavefront per stream: the kernel is
 // register heavy, and a 4-wave workgroup per stream took every SIMD of the chip for itself while ORB's kernels on the
 // main stream stalled behind it.  With few streams nothing competes and the chain LK -> RANSAC -> refine IS the step
@@ -914,8 +922,9 @@ void geom_state_destroy(mvo_ctx* ctx) {
 template <class M, int NW = 1>
 static void launch_ransac(mvo_ctx* ctx, hipStream_t st, int nslots, const float* m1, const float* m2, int stride1, int stride2,
                           const int* d_n, double thr, double conf, int max_iters, const ModelParams& P, u8* mask, int mask_stride,
-                          double* model, int* result) {
+                          double* model, int* result, int* idx = nullptr, int idx_stride = 0) {
   RansacArgs A;
+  A.idx = idx; A.idx_stride = idx_stride;
   A.m1 = m1; A.m2 = m2; A.stride1 = stride1; A.stride2 = stride2; A.n = d_n;
   A.thr = thr; A.conf = conf; A.max_iters = max_iters; A.cap = ctx->maxpts; A.P = P;
   A.mask = mask; A.mask_stride = mask_stride; A.model = model; A.result = result;
@@ -945,10 +954,9 @@ int geom_pnp(mvo_ctx* ctx, int nslots, const float* obj, const float* img, const
   {
     ProfScope ps(ctx, "pnp_ransac", st);
     launch_ransac<PnPModel>(ctx, st, nslots, obj, img, ctx->maxpts * 3, ctx->maxpts * 2, d_n, (double)reproj, conf, iters, P, mask, ctx->maxpts,
-                            model, result);
+                            model, result, inl, ctx->maxpts);   // + the ordered inlier list and its length (result[5])
   }
   ProfScope ps2(ctx, "pnp_refine", st);
-  hipLaunchKernelGGL(mask_to_indices_kernel, dim3(nslots), dim3(1024), 0, st, mask, ctx->maxpts, d_n, inl, ctx->maxpts, result);
   PnpRefineArgs R;
   R.obj = obj; R.img = img; R.stride_pts = ctx->maxpts; R.inl = inl; R.result = result; R.model = model; R.n = d_n; R.pose = pose; R.cam = P.cam;
   const bool wide = ctx->refine_waves ? ctx->refine_waves == 4 : nslots <= 64;
