@@ -494,8 +494,24 @@ static int pipe_side_streams(mvo_ctx* ctx) {
   return MVO_OK;
 }
 
+static int batch_step_enqueue_and_collect(mvo_ctx* ctx, int frame_idx, unsigned stages, mvo_step_result* out);
+
+// An error return in the middle of a step must not leave work queued on the side streams: the next call would start on
+// buffers they still write.  Drain them (and the main stream) before handing the status back.
 extern "C" int mvo_batch_step(mvo_ctx* ctx, int frame_idx, unsigned stages, mvo_step_result* out) {
   if (!ctx || !ctx->pipe || !out) return MVO_E_ARG;
+  const int rc = batch_step_enqueue_and_collect(ctx, frame_idx, stages, out);
+  if (rc != MVO_OK) {
+    PipeState* p = ctx->pipe;
+    if (p->s_lk) (void)hipStreamSynchronize(p->s_lk);
+    if (p->s_pnp) (void)hipStreamSynchronize(p->s_pnp);
+    if (p->s_hf) (void)hipStreamSynchronize(p->s_hf);
+    (void)hipStreamSynchronize(ctx->stream);
+  }
+  return rc;
+}
+
+static int batch_step_enqueue_and_collect(mvo_ctx* ctx, int frame_idx, unsigned stages, mvo_step_result* out) {
   PipeState* p = ctx->pipe;
   { int rcs = pipe_side_streams(ctx); if (rcs) return rcs; }
   MatchState* m = ctx->match;
