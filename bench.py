@@ -349,15 +349,27 @@ def main():
                     rest = pool.map(_oracle_stream, jobs[1:])
                 t_all = time.perf_counter() - t0
                 allr += [r[0] for r in rest]
-            mism, rt_err, checked, worst, ill = 0, 0.0, 0, None, 0
+            # A stream whose ORACLE pose stops being a pose (LM diverged from an ill-conditioned DLT start: |rvec| > pi or |tvec| > 1e3,
+            # DESIGN 5) follows garbage from there on, on the CPU and on the device alike but not the same garbage: its later
+            # frames are counted, not compared.  Everything before a stream's first such frame must agree.
+            mism, rt_err, checked, worst, ill, mism_after, first_bad = 0, 0.0, 0, None, 0, 0, None
             for s in range(cpu_n):
+                diverged = False
                 for k, e in enumerate(allr[s]):
                     o = rec[0][k][s]
                     checked += 1
-                    mism += sum(int(getattr(o, key)) != int(e[key]) for key in INT_KEYS)
-                    if (e["flags"] & _lib.STEP_POSE) and (np.linalg.norm(e["rvec"]) > np.pi or np.linalg.norm(e["tvec"]) > 1e3):
-                        ill += 1      # the ORACLE's own pose is not a pose (LM diverged from an ill-conditioned DLT start): counted, not compared
-                    elif e["flags"] & _lib.STEP_POSE:
+                    bad_pose = bool(e["flags"] & _lib.STEP_POSE) and (np.linalg.norm(e["rvec"]) > np.pi or np.linalg.norm(e["tvec"]) > 1e3)
+                    if bad_pose:
+                        ill += 1
+                        diverged = True
+                    bad = [key for key in INT_KEYS if int(getattr(o, key)) != int(e[key])]
+                    if diverged:
+                        mism_after += len(bad)
+                        continue
+                    mism += len(bad)
+                    if bad and first_bad is None:
+                        first_bad = {"stream": s, "frame": k + 1, "keys": bad}
+                    if e["flags"] & _lib.STEP_POSE:
                         err = max(float(np.abs(rodrigues(o.rvec) - rodrigues(e["rvec"])).max()),
                                   float(np.abs(np.array(o.tvec) - e["tvec"]).max() / max(1.0, float(np.linalg.norm(e["tvec"])))))
                         if err > rt_err:
@@ -374,6 +386,8 @@ def main():
             line["rt_max_abs_err"] = rt_err
             line["rt_worst"] = worst
             line["rt_frames_oracle_pose_diverged"] = ill
+            line["int_mismatches_after_oracle_divergence"] = mism_after
+            line["first_mismatch"] = first_bad
             line["parity_checked"] = f"{cpu_n} streams x {len(allr[0])} frames of context 0 (warm-up + timed steps) vs the CPU oracle: {checked} frame results"
             line["cpu_baseline"] = {"value": round(n1 / t1, 3), "unit": "frames/s", "cores": 1, "kind": "port",
                                     "sample": f"oracle (CPU restatement of OpenCV-4.6 semantics, not OpenCV) behind the reference's Tracker "
