@@ -584,11 +584,17 @@ __device__ __forceinline__ void lk_track_group(const LkArgs& A, LkGroupLds& S, c
 #ifndef LK_WAVES_PER_EU
 #define LK_WAVES_PER_EU 3
 #endif
+#ifndef LK_PRIO
+#define LK_PRIO 1
+#endif
 #ifndef LK_RESIDENT_PER_CU
 #define LK_RESIDENT_PER_CU (4 * LK_WAVES_PER_EU)
 #endif
 __global__ __launch_bounds__(64, LK_WAVES_PER_EU) void lk_track_kernel(LkArgs A) {
   __shared__ LkGroupLds lds[LK_G];
+#if LK_PRIO > 0
+  __builtin_amdgcn_s_setprio(LK_PRIO);   // issue priority over other contexts' image kernels that share the SIMD (the RANSAC chains use 3)
+#endif
   const int lane = threadIdx.x, g = lane >> 4, l = lane & 15;
   LkGroupLds& S = lds[g];
   if (A.work_slot) {
