@@ -502,7 +502,7 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
 #endif
   double param[6] = {0, 0, 0, 0, 0, 0};
   // ---- Mc, MM ------------------------------------------------------------------------------------------------
-  double acc[78];
+  double acc[45];
   double Mc[3];
   {
     double v[3] = {0, 0, 0};
@@ -642,28 +642,63 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
       }
       return;
     }
-    double LL[78];
-    for (int k = 0; k < 78; k++) acc[k] = 0;
-    for (int i = tid; i < count; i += PR_T) {
-      double M[3], m[2]; ptM(i, M); ptm(i, m);
-      double xu, yu;
-      gm_undistort_point(cam, m[0], m[1], xu, yu);
-      double x = -xu, y = -yu;
-      double l0[12] = {M[0], M[1], M[2], 1., 0, 0, 0, 0, x * M[0], x * M[1], x * M[2], x};
-      double l1[12] = {0, 0, 0, 0, M[0], M[1], M[2], 1., y * M[0], y * M[1], y * M[2], y};
-      int q = 0;
-      for (int a = 0; a < 12; a++)
-        for (int b = a; b < 12; b++) acc[q++] += l0[a] * l0[b] + l1[a] * l1[b];
+    // DLT normal matrix L^T L (12 x 12) with rows l0 = [P 0 x P], l1 = [0 P y P], P = [M 1]: of its 78 upper entries
+    // block (0..3, 4..7) is zero, block (4..7, 4..7) repeats block (0..3, 0..3) term for term, and the others are sums of
+    // P_a P_b, P_a (x P_c), P_a (y P_c) and (x P_a)(x P_b) + (y P_a)(y P_b) - 52 accumulators instead of 78.  Same products,
+    // same order over the points; the reduced sums go straight into the LDS matrix.
+    double* L = s_mat;
+    {
+      double A0[10], AX[16], AY[16], A2[10];
+      for (int k = 0; k < 10; k++) { A0[k] = 0; A2[k] = 0; }
+      for (int k = 0; k < 16; k++) { AX[k] = 0; AY[k] = 0; }
+      for (int i = tid; i < count; i += PR_T) {
+        double M[3], m[2]; ptM(i, M); ptm(i, m);
+        double xu, yu;
+        gm_undistort_point(cam, m[0], m[1], xu, yu);
+        const double x = -xu, y = -yu;
+        const double P[4] = {M[0], M[1], M[2], 1.};
+        const double xP[4] = {x * M[0], x * M[1], x * M[2], x}, yP[4] = {y * M[0], y * M[1], y * M[2], y};
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+#pragma unroll
+          for (int b = a; b < 4; b++) { A0[q] += P[a] * P[b]; A2[q] += xP[a] * xP[b] + yP[a] * yP[b]; q++; }
+#pragma unroll
+          for (int c = 0; c < 4; c++) { AX[4 * a + c] += P[a] * xP[c]; AY[4 * a + c] += P[a] * yP[c]; }
+        }
+      }
+      double o[16];
+      block_sum<10, PR_NW>(A0, s_red, o);
+      if (tid == 0) {
+        int q = 0;
+        for (int a = 0; a < 4; a++)
+          for (int b = a; b < 4; b++) {
+            L[a * 12 + b] = o[q]; L[b * 12 + a] = o[q];
+            L[(4 + a) * 12 + 4 + b] = o[q]; L[(4 + b) * 12 + 4 + a] = o[q];
+            q++;
+          }
+        for (int a = 0; a < 4; a++)
+          for (int b = 0; b < 4; b++) { L[a * 12 + 4 + b] = 0; L[(4 + b) * 12 + a] = 0; }
+      }
+      block_sum<16, PR_NW>(AX, s_red, o);
+      if (tid == 0)
+        for (int a = 0; a < 4; a++)
+          for (int c = 0; c < 4; c++) { L[a * 12 + 8 + c] = o[4 * a + c]; L[(8 + c) * 12 + a] = o[4 * a + c]; }
+      block_sum<16, PR_NW>(AY, s_red, o);
+      if (tid == 0)
+        for (int a = 0; a < 4; a++)
+          for (int c = 0; c < 4; c++) { L[(4 + a) * 12 + 8 + c] = o[4 * a + c]; L[(8 + c) * 12 + 4 + a] = o[4 * a + c]; }
+      block_sum<10, PR_NW>(A2, s_red, o);
+      if (tid == 0) {
+        int q = 0;
+        for (int a = 0; a < 4; a++)
+          for (int b = a; b < 4; b++) { L[(8 + a) * 12 + 8 + b] = o[q]; L[(8 + b) * 12 + 8 + a] = o[q]; q++; }
+      }
     }
-    block_sum<78, PR_NW>(acc, s_red, LL);
     PR_TICK(0)
     if (tid == 0) {
-      double* L = s_mat;
       double* LV = s_mat + 144;
       double* LW = s_mat + 288;
-      int q = 0;
-      for (int a = 0; a < 12; a++)
-        for (int b = a; b < 12; b++) { L[a * 12 + b] = LL[q]; L[b * 12 + a] = LL[q]; q++; }
       // cvSVD(&_LL, &_LW, 0, &_LV, MODIFY_A + V_T): Vt; run the one-sided Jacobi on L^T (= L)
       gl_jacobi_svd12_lds<true>((gl_lds_double*)L, (gl_lds_double*)LW, (gl_lds_double*)LV);
       double* RRt = LV + 11 * 12;
