@@ -237,6 +237,33 @@ def test_lk_edge_cases(ctx720, frames480):
     _check_lk(ctx720, small, b[:101, :87], sp)
 
 
+def test_lk_four_points_per_wavefront_grouping(ctx720, frames480):
+    """The kernel tracks four points per wavefront, one per DPP row: every group size (1 .. 9 points), groups whose rows take
+    different branches (a point outside the image next to tracked ones, a point on flat texture, border points whose tiles
+    take the reflect path beside interior ones) and large per-point motion differences (different iteration counts in one
+    wavefront) must give each point what it gets alone - bit for bit what the oracle gives."""
+    a, b = frames480[0], frames480[2]
+    rng = np.random.default_rng(12)
+    k, _ = O.orb_detect_and_compute(a, 1000)
+    good = np.stack([k["x"], k["y"]], 1).astype(np.float32)
+    special = np.array([[-30, -30], [2, 2], [637.5, 477.5], [320, -3], [5000, 5000], [0.5, 240], [639, 1]], np.float32)
+    for n in range(1, 10):
+        for trial in range(3):
+            idx = rng.choice(len(good), n, replace=False)
+            pts = good[idx].copy()
+            m = rng.integers(0, n + 1)                     # replace m of them by border / outside points, anywhere in the group
+            pos = rng.choice(n, m, replace=False)
+            pts[pos] = special[rng.choice(len(special), m)]
+            gp, gs, ge = _check_lk(ctx720, a, b, pts)
+            for i in range(n):                             # and the same as each point tracked on its own
+                p1, s1, e1 = ctx720.lk_track(a, b, pts[i:i + 1])
+                assert np.array_equal(p1[0], gp[i]) and s1[0] == gs[i] and e1[0] == ge[i], (n, trial, i)
+    # a textured image against a flat one: every row fails at a different level / iteration
+    flat = np.full_like(a, 90)
+    _check_lk(ctx720, a, flat, good[:37])
+    _check_lk(ctx720, flat, a, good[:37])
+
+
 def test_lk_colour_input_must_be_replicated_mono(ctx480, frames480):
     """The reference tracks on the BGR8 image (src/mono_vo.cpp:94 -> src/tracker.cpp:68): three channels in every LK sum.  The
     device tracks one plane with the sums scaled by lk_channels, which is the same thing only for mono8 replicated to BGR8
