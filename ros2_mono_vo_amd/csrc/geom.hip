@@ -207,7 +207,9 @@ __global__ __launch_bounds__(64 * NW, RS_WAVES_PER_EU) void ransac_kernel(Ransac
     const int cand = lane < cpw ? wave * cpw + lane : -1;     // this thread's hypothesis of the round
     const int want = min(ch, s_ctl[4] - s_ctl[3]);            // hypotheses the round can consume (uniform)
     float ms1[M::MP * M::PT1], ms2[M::MP * M::PT2];
-    if (s_qn < want) {   // uniform
+    // refill until the round is full (checkSubset may reject most of a refill); every refill's candidates are accounted for in
+    // draw order, and a refill only starts below `want` <= RS_CH queued candidates, so the queue cannot overflow
+    for (int rf = 0; rf < (M::OVERDRAW ? 4 : 1) && s_qn < want && !s_ctl[1]; rf++) {   // uniform
       // ---- 1. candidate samples, OpenCV's getSubset draw order (sequential RNG stream, lane 0) ----------
       const int ndraw = M::OVERDRAW ? RS_DR : ch;
       const int q0 = s_qn;
@@ -266,6 +268,7 @@ __global__ __launch_bounds__(64 * NW, RS_WAVES_PER_EU) void ransac_kernel(Ransac
         s_ctl[5] = run;
         if (abort_) s_ctl[1] = 1;
       }
+      __syncthreads();
     }
     if (tid < RS_CH) {
       s_nmodels[tid] = 0;
@@ -593,7 +596,7 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
         for (int j = 0; j < 9; j++)
           for (int k = j; k < 9; k++) { L[j * 9 + k] = LtL[q]; L[k * 9 + j] = LtL[q]; q++; }
         gl_ldsd* Wl = (gl_ldsd*)(s_mat + 2 * 144);   // 9 of the 16 doubles behind the two matrices
-        gl_jacobi_eigen9_lds((gl_ldsd*)L, Wl, (gl_ldsd*)V);
+        gl_jacobi_eigen9_lds<false>((gl_ldsd*)L, Wl, (gl_ldsd*)V);
         for (int i = 0; i < 9; i++) W[i] = Wl[i];
         double invHnorm[9] = {1. / smx, 0, c4[0], 0, 1. / smy, c4[1], 0, 0, 1};
         double Hnorm2[9] = {sMx, 0, -c4[2] * sMx, 0, sMy, -c4[3] * sMy, 0, 0, 1};

@@ -132,7 +132,12 @@ __device__ GL_NOINLINE void gl_jacobi_eigen(double* A, int n, double* W, double*
 // candidates the same way, and the indR / indC entries of the two rotated rows come from the freshly rotated values in
 // registers - they ARE rows / columns k and l - instead of being re-read.  Loops run over the static range 0..8 with
 // predicates, so the per-lane index arrays stay in registers (no scratch).  A: upper triangle used, destroyed.
+// PACKED: A holds only the upper triangle, row after row (45 doubles: entry (r, c), r <= c, at r (17 - r) / 2 + c) - the
+// routine never touches the lower one - which lets the homography RANSAC keep 96 instead of 64 workspaces in LDS.
 typedef __attribute__((address_space(3))) double gl_ldsd;
+template <bool PACKED>
+__device__ __forceinline__ int gl_tri9(int r) { return PACKED ? (r * (17 - r)) >> 1 : 9 * r; }   // offset of row r; entry (r, c) at gl_tri9(r) + c
+template <bool PACKED>
 __device__ GL_NOINLINE void gl_jacobi_eigen9_lds(gl_ldsd* A, gl_ldsd* W, gl_ldsd* V) {
   constexpr int n = 9;
   const double eps = DBL_EPSILON;
@@ -143,20 +148,20 @@ __device__ GL_NOINLINE void gl_jacobi_eigen9_lds(gl_ldsd* A, gl_ldsd* W, gl_ldsd
   for (int i = 0; i < n; i++) V[i * n + i] = 1;
 #pragma unroll
   for (int k = 0; k < n; k++) {
-    W[k] = A[(n + 1) * k];
+    W[k] = A[gl_tri9<PACKED>(k) + k];
     indR[k] = 0; indC[k] = 0;
     if (k < n - 1) {
       int m = k + 1;
-      double mv = fabs(A[n * k + m]);
+      double mv = fabs(A[gl_tri9<PACKED>(k) + m]);
 #pragma unroll
-      for (int i = k + 2; i < n; i++) { const double val = fabs(A[n * k + i]); if (mv < val) mv = val, m = i; }
+      for (int i = k + 2; i < n; i++) { const double val = fabs(A[gl_tri9<PACKED>(k) + i]); if (mv < val) mv = val, m = i; }
       indR[k] = m;
     }
     if (k > 0) {
       int m = 0;
       double mv = fabs(A[k]);
 #pragma unroll
-      for (int i = 1; i < k; i++) { const double val = fabs(A[n * i + k]); if (mv < val) mv = val, m = i; }
+      for (int i = 1; i < k; i++) { const double val = fabs(A[gl_tri9<PACKED>(i) + k]); if (mv < val) mv = val, m = i; }
       indC[k] = m;
     }
   }
@@ -168,9 +173,9 @@ __device__ GL_NOINLINE void gl_jacobi_eigen9_lds(gl_ldsd* A, gl_ldsd* W, gl_ldsd
     // written with selects: a branch per predicate made the loop body ~1500 instructions long ------------------------
     double pr[n - 1], pc[n - 1];
 #pragma unroll
-    for (int i = 0; i < n - 1; i++) pr[i] = A[n * i + indR[i]];
+    for (int i = 0; i < n - 1; i++) pr[i] = A[gl_tri9<PACKED>(i) + indR[i]];
 #pragma unroll
-    for (int i = 1; i < n; i++) pc[i - 1] = A[n * indC[i] + i];
+    for (int i = 1; i < n; i++) pc[i - 1] = A[gl_tri9<PACKED>(indC[i]) + i];
     int k = 0, l = indR[0];
     double p = pr[0], mv = fabs(pr[0]);
 #pragma unroll
@@ -190,10 +195,11 @@ __device__ GL_NOINLINE void gl_jacobi_eigen9_lds(gl_ldsd* A, gl_ldsd* W, gl_ldsd
     // ---- the 16 independent element pairs: (A[up(i,k)], A[up(i,l)]) and (V[k][i], V[l][i]); loads first ---------------
     int a0i[n], a1i[n];
     double a0[n], a1[n], v0[n], v1[n];
+    const int tk = gl_tri9<PACKED>(k), tl = gl_tri9<PACKED>(l);
 #pragma unroll
     for (int i = 0; i < n; i++) {
-      a0i[i] = i < k ? n * i + k : n * k + i;
-      a1i[i] = i < l ? n * i + l : n * l + i;
+      a0i[i] = i < k ? gl_tri9<PACKED>(i) + k : tk + i;
+      a1i[i] = i < l ? gl_tri9<PACKED>(i) + l : tl + i;
       a0[i] = A[a0i[i]]; a1[i] = A[a1i[i]];
     }
 #pragma unroll

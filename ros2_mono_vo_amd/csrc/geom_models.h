@@ -27,12 +27,18 @@ struct ModelParams { CamK cam; };
 // ---------------------------------------------------------------------------------------------------
 // Homography, 4 points (HomographyEstimatorCallback)
 // ---------------------------------------------------------------------------------------------------
-// Homography rounds: RS_H_NW wavefronts per stream, RS_H_CH hypotheses each (64 per round, 106 KB of LDS workspaces)
+// Homography rounds: RS_H_NW wavefronts per stream, RS_H_CH hypotheses each.  A hypothesis' workspace is 135 doubles (LtL as
+// packed upper triangle, W, V); 4 x 16 = 64 per round is 82 KB of LDS (106 KB with the full 9 x 9 matrix before), 4 x 24 =
+// 96 per round 124 KB.  One stream, 2000 iterations, 20 % outliers (profiles/tools/ransac_h_wall.py): 4 x 16 13.4 ms, 6 x 16
+// 12.8 ms (two SIMDs carry two wavefronts: a round takes as much longer as it is wider), 4 x 24 and 3 x 32 9.9 ms, 2 x 48
+// 13.7 ms, 1 x 64 24.7 ms - the f64 pipe works through a wavefront in quarters of 16 lanes and skips empty ones.  In the
+// bench (four contexts) the wider round does not pay: 72.5 k frames/s against 73.3 k for 4 x 16 over three runs each -
+// the homography stage is 0.4 ms shorter per step, the other contexts' LK wavefronts find less LDS - so 4 x 16 it is.
 #ifndef RS_H_NW
 #define RS_H_NW 4
 #endif
 #ifndef RS_H_CH
-#define RS_H_CH (64 / RS_H_NW)
+#define RS_H_CH 16
 #endif
 #ifndef RS_H_OVERDRAW
 #define RS_H_OVERDRAW 1
@@ -42,7 +48,13 @@ struct HModel {
   // 16 hypotheses per round, every round in LDS (16 x 193 doubles = 25 KB): a 64-wide round with 48 workspaces in
   // private memory took 2.85 ms against 0.8 ms for an LDS round, i.e. more per hypothesis; wider LDS rounds (24, 32)
   // made the workgroup wait for LDS beside the image kernels
-  static constexpr int CH = RS_H_CH, WS = 81 + 9 + 81;  // LtL, W, V
+  // LtL, W, V.  In LDS (the RANSAC kernel) LtL is the packed upper triangle (45): 135 doubles per hypothesis; anywhere
+  // else (host checks of this header) the generic routine wants the full matrix
+#if defined(__HIP_DEVICE_COMPILE__)
+  static constexpr int CH = RS_H_CH, WS = 45 + 9 + 81;
+#else
+  static constexpr int CH = RS_H_CH, WS = 81 + 9 + 81;
+#endif
   static constexpr bool WIDE = false;
   static constexpr int LMEDS_BELOW = 0;
   static constexpr int MP_ALT = 0;   // no second sample size
@@ -63,7 +75,8 @@ struct HModel {
 
   // runKernel for `count` float points (count = 4 inside RANSAC)
   __device__ GL_NOINLINE static int solve_n(const float* M, const float* m, int count, double* model, double* ws) {
-    double *LtL = ws, *W = ws + 81, *V = ws + 90;
+    const bool packed = gl_is_lds(ws);
+    double *LtL = ws, *W = ws + (packed ? 45 : 81), *V = W + 9;
 #ifdef RS_TIMING
     const long long tq0 = wall_clock64();
 #endif
@@ -84,7 +97,7 @@ struct HModel {
     sMx = count / sMx; sMy = count / sMy;
     double invHnorm[9] = {1. / smx, 0, cmx, 0, 1. / smy, cmy, 0, 0, 1};
     double Hnorm2[9] = {sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1};
-    for (int i = 0; i < 81; i++) LtL[i] = 0;
+    for (int i = 0; i < (packed ? 45 : 81); i++) LtL[i] = 0;
     for (int i = 0; i < count; i++) {
       double x = (m[2 * i] - cmx) * smx, y = (m[2 * i + 1] - cmy) * smy;
       double X = (M[2 * i] - cMx) * sMx, Y = (M[2 * i + 1] - cMy) * sMy;
@@ -92,19 +105,23 @@ struct HModel {
       double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
       // rolled on purpose: fully unrolled, these loops alone take ~250 VGPRs and the wave then crowds out its SIMD
 #pragma unroll 1
+      for (int j = 0; j < 9; j++) {
+        const int row = packed ? (j * (17 - j)) >> 1 : j * 9;   // gl_tri9
+#pragma unroll 1
+        for (int k = j; k < 9; k++) LtL[row + k] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
+      }
+    }
+    if (!packed) {
+#pragma unroll 1
       for (int j = 0; j < 9; j++)
 #pragma unroll 1
-        for (int k = j; k < 9; k++) LtL[j * 9 + k] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
+        for (int k = 0; k < j; k++) LtL[j * 9 + k] = LtL[k * 9 + j];
     }
-#pragma unroll 1
-    for (int j = 0; j < 9; j++)
-#pragma unroll 1
-      for (int k = 0; k < j; k++) LtL[j * 9 + k] = LtL[k * 9 + j];
 #ifdef RS_TIMING
     const long long tq1 = wall_clock64();
 #endif
     // in the RANSAC kernel the workspace is LDS: the load-batched routine (same rotations, same values)
-    if (gl_is_lds(ws)) gl_jacobi_eigen9_lds((gl_ldsd*)LtL, (gl_ldsd*)W, (gl_ldsd*)V);
+    if (packed) gl_jacobi_eigen9_lds<true>((gl_ldsd*)LtL, (gl_ldsd*)W, (gl_ldsd*)V);
     else gl_jacobi_eigen(LtL, 9, W, V);
 #ifdef RS_TIMING
     const long long tq2 = wall_clock64();

@@ -27,9 +27,15 @@ int host_eigen9_compare(const double* A, double* W_out, double* V_out) {
   double a1[81], a2[81], w1[9], w2[9], v1[81], v2[81];
   std::memcpy(a1, A, sizeof(a1)); std::memcpy(a2, A, sizeof(a2));
   gl_jacobi_eigen(a1, 9, w1, v1);
-  gl_jacobi_eigen9_lds((gl_ldsd*)a2, (gl_ldsd*)w2, (gl_ldsd*)v2);
+  gl_jacobi_eigen9_lds<false>((gl_ldsd*)a2, (gl_ldsd*)w2, (gl_ldsd*)v2);
+  // and the packed upper-triangle layout the homography RANSAC uses in LDS
+  double ap[45], w3[9], v3[81];
+  for (int r = 0, q = 0; r < 9; r++)
+    for (int c = r; c < 9; c++) ap[q++] = A[r * 9 + c];
+  gl_jacobi_eigen9_lds<true>((gl_ldsd*)ap, (gl_ldsd*)w3, (gl_ldsd*)v3);
   std::memcpy(W_out, w2, sizeof(w2)); std::memcpy(V_out, v2, sizeof(v2));
-  return std::memcmp(w1, w2, sizeof(w1)) != 0 || std::memcmp(v1, v2, sizeof(v1)) != 0;
+  return std::memcmp(w1, w2, sizeof(w1)) != 0 || std::memcmp(v1, v2, sizeof(v1)) != 0 || std::memcmp(w1, w3, sizeof(w1)) != 0 ||
+         std::memcmp(v1, v3, sizeof(v1)) != 0;
 }
 
 int host_f7(const float* p1, const float* p2, double* F27) {
