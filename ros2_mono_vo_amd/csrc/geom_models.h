@@ -1116,6 +1116,10 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
   gm_rodrigues_m2v(R, rvec);
 }
 
+#ifndef RS_PNP_CH
+#define RS_PNP_CH 20   // EPnP hypotheses per round.  One stream (profiles/tools/pnp_wall.py, RANSAC + refine): 16 / 20 / 32 wide 1.51 / 1.47 /
+                       // 1.53 ms at 2-20 % outliers (one round: latency bound whatever the width), 4.2 / 3.2 / 2.5 ms at 40 % (fewer rounds)
+#endif
 struct PnPModel {
   static constexpr int MP = 5, MAXM = 1, MS = 6, PT1 = 3, PT2 = 2;
   // Every round is 20 wide with the workspaces in LDS (20 x 289 doubles = 46 KB): a round is latency bound, ~0.85 ms
@@ -1123,7 +1127,7 @@ struct PnPModel {
   // than the LDS rounds, and coarser when the iteration bound shrinks mid-way.  24 lanes of the earlier 300-double
   // workspace (62 KB) needed as few rounds, but a 62 KB workgroup waits for LDS beside the image kernels' workgroups
   // once 512 streams are resident (the launch took twice as long); 12 lanes need too many rounds.
-  static constexpr int CH = 20, WS = 144 + 132 + 12;  // MtM -> Ut; M (120), then dv + L (132) / the small solves' workspaces; singular values
+  static constexpr int CH = RS_PNP_CH, WS = 144 + 132 + 12;  // MtM -> Ut; M (120), then dv + L (132) / the small solves' workspaces; singular values
   static constexpr bool WIDE = false;
   static constexpr int LMEDS_BELOW = 0;
   static constexpr int MP_ALT = 4;   // four correspondences: P3P on all of them instead of RANSAC
