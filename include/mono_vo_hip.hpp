@@ -162,6 +162,96 @@ class Backend {
   int cap_ = 0;
 };
 
+// ---- frame-batch mode: B camera streams resident in one context, every one its own Tracker on the device ---------------
+// (mvo_batch_* of include/mvo.h; csrc/track.hip).  A slot is what `Tracker tracker_` + `Map map_` are for one camera in
+// src/mono_vo.cpp; `track` is Tracker::update for all of them, the output side is image_callback's pose / path / cloud
+// bookkeeping (src/mono_vo.cpp:117-152) kept per slot on the device.
+class BatchTracker {
+ public:
+  BatchTracker(int width, int height, int batch, int nfeatures = 1000, int max_points = 4096, int ring_frames = 2) : B_(batch), cap_(max_points) {
+    mvo_config cfg;
+    mvo_config_default(&cfg);
+    cfg.max_width = width; cfg.max_height = height; cfg.batch = batch; cfg.nfeatures = nfeatures; cfg.max_points = max_points;
+    cfg.ring_frames = ring_frames;
+    const int rc = mvo_create(&cfg, &ctx_);
+    if (rc != MVO_OK) throw Error(rc, "mvo_create failed (no HIP device / out of memory?)");
+  }
+  ~BatchTracker() { mvo_destroy(ctx_); }
+  BatchTracker(const BatchTracker&) = delete;
+  BatchTracker& operator=(const BatchTracker&) = delete;
+  mvo_ctx* ctx() const { return ctx_; }
+  int batch() const { return B_; }
+
+  void set_intrinsics(const Mat3& K, const double d[5]) { check(mvo_batch_set_intrinsics(ctx_, K.data(), d)); }
+  // one camera's frame into ring entry `entry` (synchronous; any encoding code of mvo.h) ...
+  void preload_frame(int slot, int entry, const Image& im) { check(mvo_batch_preload_frame(ctx_, slot, entry, im.data, im.width, im.height, im.stride, im.channels)); }
+  // ... or all B mono8 frames of an entry in one asynchronous copy (pinned memory: mvo_host_alloc)
+  void upload_async(int entry, const uint8_t* frames, int w, int h, int stride, size_t slot_stride) { check(mvo_batch_upload_async(ctx_, entry, frames, w, h, stride, slot_stride)); }
+  // the Initializer's hand-over: ORB on entry `entry`, every key-point a track; then the landmarks per slot
+  std::vector<int> seed(int entry) {
+    std::vector<int> n(B_);
+    check(mvo_batch_seed(ctx_, entry, n.data()));
+    return n;
+  }
+  std::vector<Point2f> tracks(int slot) const {
+    std::vector<Point2f> p(cap_);
+    int n = 0;
+    check(mvo_batch_get_tracks(ctx_, slot, &p[0].x, cap_, &n));
+    p.resize(n);
+    return p;
+  }
+  void set_landmarks(int slot, const std::vector<Point3f>& lm) { check(mvo_batch_set_landmarks(ctx_, slot, lm.empty() ? nullptr : &lm[0].x, (int)lm.size())); }
+  void set_policy(int policy) { check(mvo_batch_set_policy(ctx_, policy)); }
+  // Tracker::update for every slot on ring entry `entry`
+  std::vector<mvo_step_result> track(int entry) {
+    std::vector<mvo_step_result> r(B_);
+    check(mvo_batch_track(ctx_, entry, r.data()));
+    return r;
+  }
+  void track_async(int entry) { check(mvo_batch_track_async(ctx_, entry)); }
+  bool poll() const { return mvo_batch_track_poll(ctx_) != 0; }
+  std::vector<mvo_step_result> wait() {
+    std::vector<mvo_step_result> r(B_);
+    check(mvo_batch_track_wait(ctx_, r.data()));
+    return r;
+  }
+  void state(std::vector<int>& st, std::vector<int>& tracking_count) const {
+    st.assign(B_, 0); tracking_count.assign(B_, 0);
+    check(mvo_batch_get_state(ctx_, st.data(), tracking_count.data()));
+  }
+  // output side (src/mono_vo.cpp:117-152, src/utils.cpp:85-243); enable before set_landmarks
+  void enable_output(int map_capacity, int path_capacity) {
+    check(mvo_batch_enable_output(ctx_, map_capacity, path_capacity));
+    map_cap_ = map_capacity; path_cap_ = path_capacity;
+  }
+  std::vector<mvo_ros_pose> odometry() const {
+    std::vector<mvo_ros_pose> r(B_);
+    check(mvo_batch_get_odometry(ctx_, r.data()));
+    return r;
+  }
+  std::vector<std::array<double, 7>> path(int slot) const {   // position xyz, orientation xyzw per pose
+    std::vector<std::array<double, 7>> p(path_cap_);
+    int n = 0;
+    check(mvo_batch_get_path(ctx_, slot, p.empty() ? nullptr : p[0].data(), path_cap_, &n));
+    p.resize(n);
+    return p;
+  }
+  std::vector<Point3f> pointcloud(int slot) const {           // PointCloud2 payload: ROS axes, point_step 12
+    std::vector<Point3f> c(map_cap_);
+    int n = 0;
+    check(mvo_batch_get_pointcloud(ctx_, slot, c.empty() ? nullptr : &c[0].x, map_cap_, &n));
+    c.resize(n);
+    return c;
+  }
+
+ private:
+  void check(int rc) const {
+    if (rc != MVO_OK) throw Error(rc, std::string("mvo: ") + mvo_last_error(ctx_));
+  }
+  mvo_ctx* ctx_ = nullptr;
+  int B_ = 1, cap_ = 0, map_cap_ = 0, path_cap_ = 0;
+};
+
 // ---- src/feature_processor.cpp ------------------------------------------------------------------------------------------
 class FeatureProcessor {
  public:
