@@ -37,7 +37,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 ALGO_BYTES_PER_LK_POINT = 4261  # 4 levels x (24^2 + 22^2) window bytes + 21 B of point I/O
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-STAGE_TIMERS = ("frame_fanout", "lk_pyramid", "lk_track", "lk_filter", "pnp", "pnp_ransac", "pnp_refine", "ransac_h", "ransac_f", "kf_gather", "orb_detect", "orb_select",
+STAGE_TIMERS = ("frame_fanout", "lk_pyramid", "lk_worklist", "lk_track", "lk_filter", "pnp", "pnp_ransac", "pnp_refine", "ransac_h", "ransac_f", "kf_gather", "orb_detect", "orb_select",
                 "orb_blur", "orb_describe", "kf_scatter", "match", "triangulate")
 INT_KEYS = ("n_prev", "n_tracked", "pnp_ok", "n_pnp_inliers", "score_h", "score_f", "n_keypoints", "n_matches", "n_triangulated",
             "state", "flags", "tracking_count", "n_tracks")

@@ -22,6 +22,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 
 struct TrackState {
   int* d_state = nullptr;      // [B] MVO_TRACK_*
@@ -45,6 +46,7 @@ struct TrackState {
                                // 2: never a key-frame (the always-on part of the step: LK + PnP)
   bool pending = false;
   hipEvent_t ev_done = nullptr;
+  hipEvent_t ev_lk = nullptr;   // this context's latest LK launch has finished
   // output side (mvo_batch_enable_output): what MonoVO::image_callback derives from the tracker's result on every frame
   bool out_on = false;
   int map_cap = 0, path_cap = 0;
@@ -54,6 +56,17 @@ struct TrackState {
   int* d_n_path = nullptr;         // [B]
   mvo_ros_pose* d_ros = nullptr;   // [B] last_pose_ in REP-103 + tracking_valid_
 };
+
+// The LK kernel is the one launch of a step that fills the GPU by itself (persistent wavefronts on every SIMD).  Two of
+// them from different contexts cannot run side by side - the later one's wavefronts only find room as the earlier one's
+// leave - so they take turns explicitly: a context's LK launch waits for the LK launch enqueued before it, whichever
+// context that was (process-wide, one process per GPU).  MVO_LK_TURNS=0 turns the ordering off.
+static std::mutex g_lk_mu;
+static hipEvent_t g_lk_last = nullptr;
+static bool lk_turns() {
+  static const bool on = !(getenv("MVO_LK_TURNS") && atoi(getenv("MVO_LK_TURNS")) == 0);
+  return on;
+}
 
 #define TRK_ERR_KEYPOINTS 1   // a slot's key-points exceeded max_points (clamped)
 #define TRK_ERR_CAND 2        // FAST candidates exceeded the candidate capacity (clamped)
@@ -585,6 +598,7 @@ static int trk_create(mvo_ctx* ctx) {
   MVO_HIP(hipHostMalloc(&t->h_res, (size_t)B * sizeof(mvo_step_result), hipHostMallocDefault));
   MVO_HIP(hipHostMalloc(&t->h_err, sizeof(int), hipHostMallocDefault));
   MVO_HIP(hipEventCreateWithFlags(&t->ev_done, hipEventDisableTiming));
+  MVO_HIP(hipEventCreateWithFlags(&t->ev_lk, hipEventDisableTiming));
   MVO_HIP(hipMemsetAsync(t->d_state, 0, B * sizeof(int), ctx->stream));
   MVO_HIP(hipMemsetAsync(t->d_count, 0, B * sizeof(int), ctx->stream));
   MVO_HIP(hipMemsetAsync(t->d_err, 0, sizeof(int), ctx->stream));
@@ -611,6 +625,11 @@ void trk_destroy(mvo_ctx* ctx) {
   if (t->h_res) (void)hipHostFree(t->h_res);
   if (t->h_err) (void)hipHostFree(t->h_err);
   if (t->ev_done) (void)hipEventDestroy(t->ev_done);
+  if (t->ev_lk) {
+    std::lock_guard<std::mutex> lock(g_lk_mu);
+    if (g_lk_last == t->ev_lk) g_lk_last = nullptr;
+    (void)hipEventDestroy(t->ev_lk);
+  }
   delete t;
   p->trk = nullptr;
 }
@@ -716,10 +735,19 @@ extern "C" int mvo_batch_track_async(mvo_ctx* ctx, int frame_idx) {
   p->rd_pending[frame_idx] = 1;
   { ProfScope ps(ctx, "lk_pyramid"); lk_build_pyramid(ctx, cur_set, L, B, st); }
   {
-    ProfScope ps(ctx, "lk_track");
+    ProfScope ps(ctx, "lk_worklist");
     hipLaunchKernelGGL(trk_worklist_scan_kernel, dim3(1), dim3(1024), 0, st, t->d_state, ctx->d_npts, B, cap, t->d_pt_base, t->d_work_ctr,
                        t->d_flags, t->d_res);
     hipLaunchKernelGGL(trk_worklist_expand_kernel, dim3(B), dim3(256), 0, st, t->d_pt_base, t->d_work_slot);
+  }
+  if (lk_turns()) {
+    std::lock_guard<std::mutex> lock(g_lk_mu);
+    if (g_lk_last && g_lk_last != t->ev_lk) MVO_HIP(hipStreamWaitEvent(st, g_lk_last, 0));
+    { ProfScope ps(ctx, "lk_track"); lk_track_device(ctx, prev_set, cur_set, L, B, cap, st, t->d_work_slot, t->d_pt_base, t->d_work_ctr); }
+    MVO_HIP(hipEventRecord(t->ev_lk, st));
+    g_lk_last = t->ev_lk;
+  } else {
+    ProfScope ps(ctx, "lk_track");
     lk_track_device(ctx, prev_set, cur_set, L, B, cap, st, t->d_work_slot, t->d_pt_base, t->d_work_ctr);
   }
   {
