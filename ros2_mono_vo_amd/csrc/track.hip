@@ -62,7 +62,8 @@ struct TrackState {
 // leave - so they take turns explicitly: a context's LK launch waits for the LK launch enqueued before it, whichever
 // context that was (process-wide, one process per GPU).  MVO_LK_TURNS=0 turns the ordering off.
 static std::mutex g_lk_mu;
-static hipEvent_t g_lk_last = nullptr;
+static hipEvent_t g_lk_last_dev[32] = {};   // per device: a process that drives several GPUs orders each one's launches separately
+static hipEvent_t& lk_last(const mvo_ctx* ctx) { return g_lk_last_dev[(unsigned)ctx->cfg.device % 32u]; }
 static bool lk_turns() {
   static const bool on = !(getenv("MVO_LK_TURNS") && atoi(getenv("MVO_LK_TURNS")) == 0);
   return on;
@@ -627,7 +628,7 @@ void trk_destroy(mvo_ctx* ctx) {
   if (t->ev_done) (void)hipEventDestroy(t->ev_done);
   if (t->ev_lk) {
     std::lock_guard<std::mutex> lock(g_lk_mu);
-    if (g_lk_last == t->ev_lk) g_lk_last = nullptr;
+    if (lk_last(ctx) == t->ev_lk) lk_last(ctx) = nullptr;
     (void)hipEventDestroy(t->ev_lk);
   }
   delete t;
@@ -742,10 +743,11 @@ extern "C" int mvo_batch_track_async(mvo_ctx* ctx, int frame_idx) {
   }
   if (lk_turns()) {
     std::lock_guard<std::mutex> lock(g_lk_mu);
-    if (g_lk_last && g_lk_last != t->ev_lk) MVO_HIP(hipStreamWaitEvent(st, g_lk_last, 0));
+    hipEvent_t& last = lk_last(ctx);
+    if (last && last != t->ev_lk) MVO_HIP(hipStreamWaitEvent(st, last, 0));
     { ProfScope ps(ctx, "lk_track"); lk_track_device(ctx, prev_set, cur_set, L, B, cap, st, t->d_work_slot, t->d_pt_base, t->d_work_ctr); }
     MVO_HIP(hipEventRecord(t->ev_lk, st));
-    g_lk_last = t->ev_lk;
+    last = t->ev_lk;
   } else {
     ProfScope ps(ctx, "lk_track");
     lk_track_device(ctx, prev_set, cur_set, L, B, cap, st, t->d_work_slot, t->d_pt_base, t->d_work_ctr);
