@@ -58,6 +58,7 @@ def parse_args():
     ap.add_argument("--extra-steps", type=int, default=5, help="steps of the always-on and key-frame-every-frame phases (0 = skip)")
     ap.add_argument("--cpu-streams", type=int, default=None, help="streams checked against / timed on the CPU oracle (default: host cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--contexts-first", action="store_true", help="diagnostic: create every context before the first upload")
     ap.add_argument("--no-stagger", action="store_true", help="start all contexts on the same frame (key-frame steps coincide)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: rendezvous (gloo) and print the line skeleton")
     ap.add_argument("--dump-stream", type=int, default=None, help="diagnostic: save the frames + depth of this stream of context 0")
@@ -184,8 +185,11 @@ def main():
 
     # ---- contexts: frames resident in the device ring, seeded with depth landmarks -------------------------------------
     ctxs = []
+    pre = [Context(max_width=W, max_height=H, batch=B, nfeatures=args.nfeatures, max_points=4096, ring_frames=n_frames, device=local_rank)
+           for _ in range(C)] if args.contexts_first else None     # diagnostic: creation order must not matter
     for c in range(C):
-        ctx = Context(max_width=W, max_height=H, batch=B, nfeatures=args.nfeatures, max_points=4096, ring_frames=n_frames, device=local_rank)
+        ctx = pre[c] if pre else Context(max_width=W, max_height=H, batch=B, nfeatures=args.nfeatures, max_points=4096, ring_frames=n_frames,
+                                         device=local_rank)
         ctx.batch_set_intrinsics(Kmat, dcoef)
         for f in range(n_frames):
             ctx.batch_upload_async(f, frames[c, f].data_ptr(), W, H, pitch, H * pitch)     # device -> device, one copy per frame

@@ -237,6 +237,7 @@ int pipe_state_create(mvo_ctx* ctx);
 void pipe_state_destroy(mvo_ctx* ctx);
 void trk_destroy(mvo_ctx* ctx);   // track.hip
 int trk_reset(mvo_ctx* ctx);
+int trk_ring_events(mvo_ctx* ctx);                  // upload stream + ring events (idempotent)
 int trk_wait_upload(mvo_ctx* ctx, int frame_idx);   // ctx->stream waits for an asynchronous upload into ring entry frame_idx
 int trk_output_seed(mvo_ctx* ctx, int slot, const float* d_lm, int n);   // output side: the seed landmarks open the slot's map
 int trk_sync_upload(mvo_ctx* ctx);                  // host waits for the upload stream

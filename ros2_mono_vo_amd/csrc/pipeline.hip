@@ -155,7 +155,7 @@ int pipe_state_create(mvo_ctx* ctx) {
   MVO_HIP(hipHostMalloc(&p->h_ints, (size_t)ctx->B * 64 * sizeof(int), hipHostMallocDefault));
   MVO_HIP(hipMemsetAsync(p->d_lm, 0, np * 3 * sizeof(float), ctx->stream));
   MVO_HIP(hipMemsetAsync(p->d_kf_pts, 0, np * 2 * sizeof(float), ctx->stream));
-  return MVO_OK;
+  return trk_ring_events(ctx);   // the upload stream right behind the compute stream (see there)
 }
 
 void pipe_state_destroy(mvo_ctx* ctx) {
