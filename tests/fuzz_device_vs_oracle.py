@@ -2,7 +2,10 @@
 Four minutes of random small problems, the HIP path through the C ABI against the oracle: LK with random group sizes and
 mixes of interior / border / outside points, findHomography (masks and H bit for bit), findFundamentalMat (masks),
 solvePnPRansac incl. n = 4 / 5 / 6 (inlier lists bit for bit, poses to 1e-6).  Exit code 1 on any mismatch.
-Round 2, seed 7: 8657 LK + 8657 H + 8507 F + 8657 PnP cases, 0 mismatches."""
+Then a minute of ORB on random crops (key-points incl. order, descriptors), the matcher on random descriptors with ties, and
+findEssentialMat (masks) + recoverPose + triangulatePoints.
+Round 2: seed 7 (first part only, 4 min): 8657 LK + 8657 H + 8507 F + 8657 PnP cases; seed 11: 6476 LK + 6476 H + 6351 F +
+6476 PnP + 1349 ORB + 1349 matcher + 1349 E / recoverPose / triangulate cases - 0 mismatches in both."""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))   # tests/ holds the oracle binding
@@ -17,7 +20,7 @@ with Context(max_width=640, max_height=480, max_points=8192) as ctx:
     k, _ = O.orb_detect_and_compute(fr[0], 1000)
     good = np.stack([k["x"], k["y"]], 1).astype(np.float32)
     n_lk = n_h = n_f = n_p = 0
-    while time.time() - t0 < 240:
+    while time.time() - t0 < 180:
         # ---- LK: random group sizes, random mix of good / border / outside / sub-pixel points, random frame pair
         n = int(rng.integers(1, 40))
         pts = good[rng.choice(len(good), n)].copy() + rng.uniform(-0.5, 0.5, (n, 2)).astype(np.float32)
@@ -59,5 +62,44 @@ with Context(max_width=640, max_height=480, max_points=8192) as ctx:
                 (ok and np.linalg.norm(orv) < 3 and (np.abs(rv - orv).max() > 1e-6 * max(1, np.abs(orv).max()) or np.abs(tv - otv).max() > 1e-6 * max(1, np.abs(otv).max()))):
             bad += 1; print("PNP MISMATCH n", len(idx), ok, rc, flush=True)
         n_p += 1
-print(f"fuzz done: LK {n_lk} H {n_h} F {n_f} PnP {n_p} cases, mismatches {bad}, {time.time() - t0:.0f} s", flush=True)
+    # ---- second part (60 s): ORB on random crops / sizes, the matcher on random descriptors, E RANSAC + recoverPose + triangulation
+    n_orb = n_m = n_e = 0
+    base = synth.gen_stream(640, 480, 0x5EED0077, 1)[0]
+    t1 = time.time()
+    while time.time() - t1 < 60:
+        w, h = int(rng.integers(64, 641)), int(rng.integers(64, 481))
+        x0, y0 = int(rng.integers(0, 641 - w)), int(rng.integers(0, 481 - h))
+        img = np.ascontiguousarray(base[y0:y0 + h, x0:x0 + w])
+        kps, desc = ctx.orb_detect_and_compute(img)
+        okps, odesc = O.orb_detect_and_compute(img, 1000)
+        if not (len(kps) == len(okps) and np.array_equal(desc, odesc) and all(np.array_equal(kps[f], okps[f]) for f in ("x", "y", "angle", "response", "octave"))):
+            bad += 1; print("ORB MISMATCH", w, h, x0, y0, len(kps), len(okps), flush=True)
+        n_orb += 1
+        nq, nt = int(rng.integers(0, 300)), int(rng.integers(0, 300))
+        q = rng.integers(0, 256, (nq, 32), dtype=np.uint8); t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+        if nq and nt >= 2 and rng.integers(0, 2):
+            t[rng.integers(0, nt)] = t[0]; q[0] = t[0]
+        ratio = float(rng.choice([0.5, 0.7, 0.9, 1.0]))
+        if not np.array_equal(ctx.match_knn2_ratio(q, t, ratio), O.match_knn2_ratio(q, t, ratio)):
+            bad += 1; print("MATCH MISMATCH", nq, nt, ratio, flush=True)
+        n_m += 1
+        P = int(rng.integers(5, 300)); outl = float(rng.choice([0.0, 0.1, 0.3]))
+        sc = synth.gen_scene(P, int(rng.integers(0, 2**31)), outlier_frac=outl)
+        ok, mask, E, ni = ctx.find_essential_ransac(sc["p1"], sc["p2"], sc["K"])
+        r, omask, oE, st = O.find_essential_ransac(sc["p1"], sc["p2"], sc["K"])
+        if not (ok == (r > 0) and np.array_equal(mask, omask)):
+            bad += 1; print("E MISMATCH", P, outl, flush=True)
+        elif ok:
+            g, R, tt, m2 = ctx.recover_pose(oE, sc["p1"], sc["p2"], sc["K"], omask)
+            og, oR, ot, om2 = O.recover_pose(oE, sc["p1"], sc["p2"], sc["K"], omask)
+            if not (g == og and np.array_equal(m2, om2) and np.abs(R - oR).max() < 1e-9 and np.abs(tt - ot).max() < 1e-9):
+                bad += 1; print("RECOVERPOSE MISMATCH", P, outl, g, og, flush=True)
+            K = sc["K"]
+            P1 = K @ np.hstack([np.eye(3), np.zeros((3, 1))]); P2 = K @ np.hstack([oR, ot.reshape(3, 1)])
+            X3 = ctx.triangulate(P1, P2, sc["p1"], sc["p2"])
+            oX3, _ = O.triangulate(P1, P2, sc["p1"], sc["p2"])
+            if not np.array_equal(X3, oX3):
+                bad += 1; print("TRIANGULATE MISMATCH", P, flush=True)
+        n_e += 1
+print(f"fuzz done: LK {n_lk} H {n_h} F {n_f} PnP {n_p} ORB {n_orb} match {n_m} E/recoverPose/triangulate {n_e} cases, mismatches {bad}, {time.time() - t0:.0f} s", flush=True)
 sys.exit(1 if bad else 0)
