@@ -32,13 +32,14 @@ struct ModelParams { CamK cam; };
 // 96 per round 124 KB.  One stream, 2000 iterations, 20 % outliers (profiles/tools/ransac_h_wall.py): 4 x 16 13.4 ms, 6 x 16
 // 12.8 ms (two SIMDs carry two wavefronts: a round takes as much longer as it is wider), 4 x 24 and 3 x 32 9.9 ms, 2 x 48
 // 13.7 ms, 1 x 64 24.7 ms - the f64 pipe works through a wavefront in quarters of 16 lanes and skips empty ones.  In the
-// bench (four contexts) the wider round does not pay: 72.5 k frames/s against 73.3 k for 4 x 16 over three runs each -
-// the homography stage is 0.4 ms shorter per step, the other contexts' LK wavefronts find less LDS - so 4 x 16 it is.
+// bench (four contexts) the 96-wide round first did not pay (72.5 k against 73.3 k frames/s over three runs each: the
+// other contexts' LK wavefronts found less LDS); with the LK launches taking turns it does: 73.0 k against 71.0 k, the
+// homography stage 2.3 instead of 2.8 ms per step.
 #ifndef RS_H_NW
 #define RS_H_NW 4
 #endif
 #ifndef RS_H_CH
-#define RS_H_CH 16
+#define RS_H_CH 24
 #endif
 #ifndef RS_H_OVERDRAW
 #define RS_H_OVERDRAW 1
