@@ -27,3 +27,12 @@ def test_dry_run_single_process():
 def test_gpus_2_spawns_two_ranks():
     d = run("--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1")
     assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and d["steps"] == 3 and d["warmup"] == 1
+
+
+def test_usable_cores_respects_the_container_quota():
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    n = bench.usable_cores()
+    assert 1 <= n <= (os.cpu_count() or 1) and n <= len(os.sched_getaffinity(0))

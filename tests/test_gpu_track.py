@@ -278,3 +278,37 @@ def test_output_side_on_the_device_matches_the_node_bookkeeping():
                 assert np.abs(a[:3] - b["position"]).max() < 1e-9 and np.abs(a[3:] - b["orientation"]).max() < 1e-9
         # every seed observation has a landmark, so a slot's FIRST key-frame adds none; the fast mover's later ones do
         assert grew[1] and not valid[2] and len(paths[2].poses) < N - 1 == len(paths[1].poses)   # ... and the cut stream went LOST
+
+
+def test_output_side_capacity_and_misuse():
+    """The output side's limits: getters before mvo_batch_enable_output are MVO_E_ARG; a slot whose seed landmarks or path exceed
+    the capacities keeps the first `capacity` entries and the step reports MVO_E_CAPACITY (results still delivered)."""
+    from ros2_mono_vo_amd import MvoError
+    N = 6
+    K = synth.default_K(TS.W, TS.H)
+    fr, d0 = TS.stream("lateral", N)
+    with Context(max_width=TS.W, max_height=TS.H, batch=1, nfeatures=1000, max_points=4096, ring_frames=N) as ctx:
+        ctx.batch_set_intrinsics(K)
+        with pytest.raises(MvoError) as ei:
+            ctx._out_caps = (16, 16)
+            ctx.batch_get_pointcloud(0)
+        assert ei.value.code == _lib.MVO_E_ARG
+        ctx.batch_enable_output(map_capacity=100, path_capacity=2)
+        for f in range(N):
+            ctx.batch_preload_frame(0, f, fr[f])
+        n = ctx.batch_seed(0)[0]
+        assert n > 100
+        lm = TS.depth_landmarks(K, d0)(ctx.batch_get_tracks(0))
+        ctx.batch_set_landmarks(0, lm)                      # 100 of the n landmarks fit the cloud
+        with pytest.raises(MvoError) as ei:
+            ctx.batch_track(1)                               # ... which the next step reports
+        assert ei.value.code == _lib.MVO_E_CAPACITY
+        cloud = ctx.batch_get_pointcloud(0)
+        from ros2_mono_vo_amd import ros_io
+        assert len(cloud) == 100 and cloud.tobytes() == ros_io.pointcloud2(lm[:100], 0)["data"]
+        ctx.batch_track(2)                                   # path entry 2 of 2
+        with pytest.raises(MvoError) as ei:
+            ctx.batch_track(3)                               # a third pose does not fit the path
+        assert ei.value.code == _lib.MVO_E_CAPACITY and len(ctx.batch_get_path(0)) == 2
+        st, _ = ctx.batch_get_state()
+        assert st[0] == _lib.TRACK_TRACKING                  # the tracker itself is unaffected
