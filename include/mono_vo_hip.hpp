@@ -6,8 +6,8 @@
 //   Tracker           src/tracker.cpp:58-333               VisualOdometry = src/mono_vo.cpp:83-131 without the ROS shell
 // Every cv:: call of the reference is one mvo_* call here (the boundary); the classes hold only bookkeeping.  Deliberate
 // host-side deviations: the id counters live in the Map instead of process-global statics (src/landmark.cpp:5,
-// src/keyframe.cpp:6) so several streams coexist; logging is dropped; a solvePnPRansac without a model throws
-// ReferenceAbort where the reference dies in cv::Rodrigues (src/tracker.cpp:315).
+// src/keyframe.cpp:6) so several streams coexist; logging is dropped; a solvePnPRansac without a model yields a frame
+// without a pose where the reference reads an uninitialised rvec (src/tracker.cpp:309-315; mvo.h MVO_STEP_PNP_FAILED).
 // The Python mirror (ros2_mono_vo_amd/vo.py) is the same code in the other language; tools/mvo_run.cpp is the harness.
 #pragma once
 #include <algorithm>
@@ -29,7 +29,6 @@
 namespace mono_vo {
 
 struct Error : std::runtime_error { int code; Error(int c, const std::string& m) : std::runtime_error(m), code(c) {} };
-struct ReferenceAbort : std::runtime_error { using std::runtime_error::runtime_error; };
 
 using KeyPoint = mvo_keypoint;   // cv::KeyPoint layout
 using DMatch = mvo_match;        // cv::DMatch layout
@@ -586,8 +585,13 @@ class Tracker {
     std::vector<Point2f> p2; std::vector<Point3f> p3;
     map_->get_observation_to_landmark_point_correspondences(nf, p2, p3);
     double rvec[3], tvec[3];
-    if (!fp_->backend->solve_pnp_ransac(p3, p2, K, d, rvec, tvec, last.n_pnp_inliers))
-      throw ReferenceAbort("solvePnPRansac found no model: cv::Rodrigues on an empty rvec");
+    if (!fp_->backend->solve_pnp_ransac(p3, p2, K, d, rvec, tvec, last.n_pnp_inliers)) {
+      // the reference ignores the return value and reads an uninitialised rvec (undefined pose); defined here as in
+      // include/mvo.h (MVO_STEP_PNP_FAILED): no pose for the frame, the count advances, the survivors carry on
+      tracking_count_from_keyframe_++;
+      prev_frame_ = std::move(nf);
+      return std::nullopt;
+    }
     nf.pose_wc = affine_inv(affine(rodrigues(rvec), tvec));
     tracking_count_from_keyframe_++;
     if (should_add_keyframe(nf) && has_parallax(nf)) add_new_keyframe(nf, K);

@@ -169,29 +169,31 @@ int mvo_triangulate(mvo_ctx* ctx, const double P1[12], const double P2[12], cons
 
 /* ==== frame-batch mode ============================================================
  * `cfg.batch` independent camera streams live in one context; every kernel launch covers all of them.
- * Frames are pre-loaded into a device ring (`cfg.ring_frames` per slot) so a step starts with its inputs
- * resident in HBM.  One step is the reference's steady-state Tracker::update (src/tracker.cpp:274-333)
- * in its worst case (key-frame work every frame), for every slot at once. */
-#define MVO_STAGE_LK 1u         /* pyrDown pyramid + LK + status/err filter  (src/tracker.cpp:58-90)   */
-#define MVO_STAGE_PNP 2u        /* solvePnPRansac                            (src/tracker.cpp:300-316) */
-#define MVO_STAGE_HF 4u         /* findHomography + findFundamentalMat       (src/tracker.cpp:237-268) */
-#define MVO_STAGE_ORB 8u        /* ORB detect + describe on the new frame    (src/tracker.cpp:185-186) */
-#define MVO_STAGE_MATCH 16u     /* knn2 + ratio vs the last key-frame        (src/tracker.cpp:190-191) */
-#define MVO_STAGE_TRIANG 32u    /* triangulate the matches                   (src/tracker.cpp:208-209) */
-#define MVO_STAGE_ALL 63u
+ * Frames live in a device ring (`cfg.ring_frames` entries of `batch` frames, >= 2 for tracking) so a step starts with its
+ * inputs resident in HBM.  One step (mvo_batch_track) is the reference's Tracker::update (src/tracker.cpp:274-333) for
+ * every slot at once, each slot on its own branch.
+ *
+ * Ring contract: LK reads level 0 of both pyramids IN PLACE from the ring - the entry tracked (or seeded) last is the
+ * "previous image" of the next step (the reference's prev_frame_.image, src/tracker.cpp:61-68).  Keep it intact until the
+ * following step has been enqueued; an asynchronous upload into it then waits on the device for that step's LK launch.
+ * Overwriting it earlier is detected: the next mvo_batch_track fails with MVO_E_ARG until mvo_batch_seed runs again. */
 
 /* Tracker state of a slot (mvo_batch_track): TrackerState of include/mono_vo/tracker.hpp:20-24 after the INITIALIZING
- * hand-over, plus ABORTED for the case the reference does not survive: solvePnPRansac finds no model, rvec stays empty
- * and cv::Rodrigues (src/tracker.cpp:315) throws out of image_callback.  LOST and ABORTED are terminal. */
+ * hand-over.  LOST is terminal (src/tracker.cpp:277-279). */
 #define MVO_TRACK_TRACKING 0
 #define MVO_TRACK_LOST 1
-#define MVO_TRACK_ABORTED 2
 /* What a slot did on this frame (mvo_step_result.flags). */
 #define MVO_STEP_LOST_NOW 1u     /* fewer than min_tracked_points survivors: LOST, no pose     (src/tracker.cpp:292-296) */
 #define MVO_STEP_POSE 2u         /* Tracker::update returned a pose (rvec / tvec are T_cw)      (src/tracker.cpp:315-316) */
 #define MVO_STEP_KF_CHECKED 4u   /* should_add_keyframe was true: H / F RANSAC ran             (src/tracker.cpp:319-320) */
 #define MVO_STEP_KEYFRAME 8u     /* has_parallax was true: add_new_keyframe ran                (src/tracker.cpp:321-322) */
-#define MVO_STEP_ABORTED_NOW 16u /* solvePnPRansac found no model (see MVO_TRACK_ABORTED) */
+/* solvePnPRansac found no model.  DELIBERATE DIVERGENCE from undefined behaviour in the reference: it ignores the return
+ * value (src/tracker.cpp:309-315); OpenCV 4.x creates rvec / tvec (3x1) before RANSAC and, without a model, assigns them
+ * from an uninitialised local Mat, so cv::Rodrigues turns whatever bytes are there into the frame's "pose" and the
+ * key-frame test runs on it.  Defined here instead: the frame has NO pose (no MVO_STEP_POSE, last pose kept), the stream
+ * stays TRACKING, tracking_count_from_keyframe_ is incremented, no key-frame test, and the LK survivors become prev_frame_
+ * (src/tracker.cpp:331) so that a later frame can recover.  Parity unpinned (no OpenCV here). */
+#define MVO_STEP_PNP_FAILED 16u
 
 typedef struct mvo_step_result {
   int n_prev;         /* points fed to LK */
@@ -200,7 +202,6 @@ typedef struct mvo_step_result {
   double rvec[3], tvec[3];
   int score_h, score_f;
   int n_keypoints, n_matches, n_triangulated;
-  /* mvo_batch_track only (mvo_batch_step leaves them 0) */
   int state;          /* MVO_TRACK_* after this frame */
   unsigned flags;     /* MVO_STEP_* */
   int tracking_count; /* tracking_count_from_keyframe_ after this frame */
@@ -216,7 +217,6 @@ int mvo_batch_seed(mvo_ctx* ctx, int frame_idx, int* n_keypoints /* [batch] */);
 int mvo_batch_get_tracks(mvo_ctx* ctx, int slot, float* pts /* cap x 2 */, int cap, int* n);
 int mvo_batch_set_landmarks(mvo_ctx* ctx, int slot, const float* xyz /* n x 3 */, int n);
 int mvo_batch_set_intrinsics(mvo_ctx* ctx, const double K[9], const double d[5]);
-int mvo_batch_step(mvo_ctx* ctx, int frame_idx, unsigned stages, mvo_step_result* out /* [batch] */);
 
 /* ---- frame-batch mode as B x Tracker::update (src/tracker.cpp:274-333), device driven ----------------------------------
  * Every slot carries its own tracker state on the device (state, tracking_count_from_keyframe_, last key-frame, tracks)
@@ -230,7 +230,7 @@ int mvo_batch_step(mvo_ctx* ctx, int frame_idx, unsigned stages, mvo_step_result
  *   mvo_batch_track_wait   block until it has finished, copy the per-slot results to out[batch] (may be NULL);
  *                          MVO_E_CAPACITY if a device-side capacity was exceeded (results clamped)
  *   mvo_batch_track        both
- *   mvo_batch_set_policy   0: the reference's key-frame policy (default); benchmarking loads (LOST / ABORTED handling
+ *   mvo_batch_set_policy   0: the reference's key-frame policy (default); benchmarking loads (LOST handling
  *                          unchanged): 1 = key-frame branch on every tracked frame (worst case), 2 = never a key-frame
  *                          (the always-on part of the step: LK + PnP)
  *   mvo_batch_get_state    MVO_TRACK_* and tracking_count_from_keyframe_ of every slot (blocks) */
@@ -260,8 +260,7 @@ int mvo_tracker_step(mvo_ctx* ctx, const uint8_t* img, int w, int h, int stride,
  *     as (z, -x, -y) float32, point_step 12.  width = *n, row_step = 12 * *n, data = the buffer.
  * mvo_batch_enable_output allocates `map_capacity` landmarks and `path_capacity` poses per slot (MVO_E_CAPACITY from
  * mvo_batch_track_wait when a slot would exceed them; the excess is dropped); call it before mvo_batch_set_landmarks.
- * The header stamps / frame ids and the fixed covariances (utils.cpp:131-146) stay with the caller's message objects.
- * A slot in MVO_TRACK_ABORTED is frozen (the reference process would have died). */
+ * The header stamps / frame ids and the fixed covariances (utils.cpp:131-146) stay with the caller's message objects. */
 typedef struct mvo_ros_pose {
   double position[3];     /* REP-103: x forward, y left, z up */
   double orientation[4];  /* x, y, z, w */
@@ -276,8 +275,9 @@ int mvo_batch_get_pointcloud(mvo_ctx* ctx, int slot, float* data /* cap x 3 */, 
 /* ---- asynchronous ingest (src/mono_vo.cpp:92-100: the image the callback hands to the tracker) ---------------------------
  * mvo_batch_upload_async copies all `batch` mono8 frames of ring entry `frame_idx` (images `slot_stride` bytes apart, rows
  * `stride` bytes apart) host -> device on a dedicated upload stream and returns at once; the step that uses the entry
- * waits for the copy on the device, and the copy waits for the step that last read the entry.  With a ring of >= 2
- * entries frame k+1 uploads while step k computes.  The host buffer must stay valid until the step that consumes it has
+ * waits for the copy on the device, and the copy waits for the last launch that reads the entry (the LK launch of the step
+ * AFTER the one the entry was tracked on, see the ring contract above).  With a ring of 2 entries the upload of frame k+1
+ * overlaps what step k does behind its LK launch, with >= 3 entries the whole step.  The host buffer must stay valid until the step that consumes it has
  * been enqueued and its wait / poll has returned; pinned memory (mvo_host_alloc, or hipHostRegister'd memory) is what
  * makes the copy asynchronous - pageable memory works but serialises. */
 int mvo_batch_upload_async(mvo_ctx* ctx, int frame_idx, const uint8_t* frames, int w, int h, int stride, size_t slot_stride);

@@ -51,7 +51,7 @@ ABI_SYMBOLS = [
     "mvo_pyrdown", "mvo_find_homography_ransac", "mvo_find_fundamental_ransac", "mvo_solve_pnp_ransac",
     "mvo_find_essential_ransac", "mvo_recover_pose", "mvo_triangulate",
     "mvo_batch_preload_frame", "mvo_batch_seed", "mvo_batch_get_tracks", "mvo_batch_set_landmarks",
-    "mvo_batch_set_intrinsics", "mvo_batch_step", "mvo_profile_enable", "mvo_profile_read", "mvo_profile_reset",
+    "mvo_batch_set_intrinsics", "mvo_profile_enable", "mvo_profile_read", "mvo_profile_reset",
     "mvo_batch_track_async", "mvo_batch_track_poll", "mvo_batch_track_wait", "mvo_batch_track", "mvo_batch_set_policy",
     "mvo_batch_get_state", "mvo_batch_upload_async", "mvo_host_alloc", "mvo_host_free", "mvo_set_intrinsics", "mvo_tracker_step",
     "mvo_batch_enable_output", "mvo_batch_get_odometry", "mvo_batch_get_path", "mvo_batch_get_pointcloud",
@@ -71,9 +71,8 @@ class RosPose(C.Structure):
     _fields_ = [("position", C.c_double * 3), ("orientation", C.c_double * 4), ("tracking_valid", C.c_int), ("has_pose", C.c_int)]
 
 
-STAGE_LK, STAGE_PNP, STAGE_HF, STAGE_ORB, STAGE_MATCH, STAGE_TRIANG, STAGE_ALL = 1, 2, 4, 8, 16, 32, 63
-TRACK_TRACKING, TRACK_LOST, TRACK_ABORTED = 0, 1, 2
-STEP_LOST_NOW, STEP_POSE, STEP_KF_CHECKED, STEP_KEYFRAME, STEP_ABORTED_NOW = 1, 2, 4, 8, 16
+TRACK_TRACKING, TRACK_LOST = 0, 1
+STEP_LOST_NOW, STEP_POSE, STEP_KF_CHECKED, STEP_KEYFRAME, STEP_PNP_FAILED = 1, 2, 4, 8, 16
 
 _lib = None
 

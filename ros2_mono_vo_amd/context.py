@@ -159,11 +159,6 @@ class Context:
         d = np.zeros(5) if d is None else np.ascontiguousarray(d, np.float64).reshape(5)
         self._check(self._L.mvo_batch_set_intrinsics(self._h, ptr(K), ptr(d)))
 
-    def batch_step(self, frame_idx, stages=_lib.STAGE_ALL):
-        res = (_lib.StepResult * int(self.cfg.batch))()
-        self._check(self._L.mvo_batch_step(self._h, int(frame_idx), C.c_uint(stages), res))
-        return res
-
     # -- frame-batch mode as B x Tracker::update (device driven, asynchronous) ---------------------------------
     def batch_track_async(self, frame_idx):
         self._check(self._L.mvo_batch_track_async(self._h, int(frame_idx)))

@@ -119,11 +119,11 @@ static void launch_pyrdown(mvo_ctx* ctx, const ImgSet& s, const ImgSet& d, int n
 struct LkLevelDesc {
   const u8* I;  // previous image, level l (slot 0)
   const u8* J;  // next image
+  size_t stride;  // bytes between slots at this level (both images): level 0 may live in the frame ring, levels 1.. in the pyramid sets
   int w, h, pitch;
 };
 struct LkArgs {
   LkLevelDesc lv[MVO_LK_MAX_LEVELS];
-  size_t slot_stride;  // bytes between slots in both pyramid sets
   int nlevels;         // levels in use (maxLevel + 1)
   const float* prev_pts;
   float* next_pts;
@@ -320,8 +320,8 @@ __device__ __forceinline__ void lk_track_group(const LkArgs& A, LkGroupLds& S, c
 
   for (int level = A.nlevels - 1; level >= 0; level--) {
     const LkLevelDesc lv = A.lv[level];
-    const u8* I = lv.I + (size_t)slot * A.slot_stride;
-    const u8* J = lv.J + (size_t)slot * A.slot_stride;
+    const u8* I = lv.I + (size_t)slot * lv.stride;
+    const u8* J = lv.J + (size_t)slot * lv.stride;
     bool go = valid;
     float px = ptx * (float)(1. / (1 << level));
     float py = pty * (float)(1. / (1 << level));
@@ -634,32 +634,43 @@ __global__ __launch_bounds__(64, LK_WAVES_PER_EU) void lk_track_kernel(LkArgs A)
 // ---------------------------------------------------------------------------------------------------
 static ImgSet lk_imgset(mvo_ctx* ctx, int set, const LkLevels& L, int level) {
   ImgSet s;
-  s.base = ctx->lk_mem[set] + ctx->lk_level_off[level];
   s.w = L.w[level]; s.h = L.h[level]; s.pitch = L.pitch[level];
-  s.slot_stride = ctx->lk_slot_bytes;
+  if (level == 0) {   // the per-call API's own level 0: slot 0 only (the frame-batch tracker reads level 0 in the frame ring)
+    s.base = ctx->lk_l0[set];
+    s.slot_stride = 0;
+  } else {
+    s.base = ctx->lk_mem[set] + ctx->lk_level_off[level];
+    s.slot_stride = ctx->lk_slot_bytes;
+  }
   return s;
 }
 
-// Build levels 1.. of pyramid set `set` for `nslots` slots (level 0 already resident).
-int lk_build_pyramid(mvo_ctx* ctx, int set, const LkLevels& L, int nslots, hipStream_t st) {
+// Build levels 1.. of pyramid set `set` for `nslots` slots.  Level 0 is `l0` (slots `l0_stride` bytes apart, e.g. an entry of
+// the frame ring) or, when null, the set's own level 0 (slot 0 only: the per-call API).
+int lk_build_pyramid(mvo_ctx* ctx, int set, const LkLevels& L, int nslots, hipStream_t st, const u8* l0, size_t l0_stride) {
   if (!st) st = ctx->stream;
-  for (int l = 1; l < L.n; l++) launch_pyrdown(ctx, lk_imgset(ctx, set, L, l - 1), lk_imgset(ctx, set, L, l), nslots, st);
+  for (int l = 1; l < L.n; l++) {
+    ImgSet src = lk_imgset(ctx, set, L, l - 1);
+    if (l == 1 && l0) { src.base = const_cast<u8*>(l0); src.slot_stride = l0_stride; }
+    launch_pyrdown(ctx, src, lk_imgset(ctx, set, L, l), nslots, st);
+  }
   return MVO_OK;
 }
 
-// Track d_prev_pts -> d_next_pts for `nslots` slots between pyramid sets prev_set and cur_set.
+// Track d_prev_pts -> d_next_pts for `nslots` slots between pyramid sets prev_set and cur_set; `prev_l0` / `cur_l0` (slots
+// `l0_stride` bytes apart) replace the sets' level 0 when given.
 int lk_track_device(mvo_ctx* ctx, int prev_set, int cur_set, const LkLevels& L, int nslots, int max_n, hipStream_t st,
-                    const int* d_work_slot, const int* d_pt_base, int* d_work_ctr) {
+                    const int* d_work_slot, const int* d_pt_base, int* d_work_ctr, const u8* prev_l0, const u8* cur_l0, size_t l0_stride) {
   if (!st) st = ctx->stream;
   LkArgs A;
   memset(&A, 0, sizeof(A));
   A.work_slot = d_work_slot; A.pt_base = d_pt_base; A.work_ctr = d_work_ctr; A.nslots = nslots;
   for (int l = 0; l < L.n; l++) {
     ImgSet p = lk_imgset(ctx, prev_set, L, l), c = lk_imgset(ctx, cur_set, L, l);
-    A.lv[l].I = p.base; A.lv[l].J = c.base;
+    A.lv[l].I = p.base; A.lv[l].J = c.base; A.lv[l].stride = p.slot_stride;
     A.lv[l].w = L.w[l]; A.lv[l].h = L.h[l]; A.lv[l].pitch = L.pitch[l];
   }
-  A.slot_stride = ctx->lk_slot_bytes;
+  if (prev_l0 && cur_l0) { A.lv[0].I = prev_l0; A.lv[0].J = cur_l0; A.lv[0].stride = l0_stride; }
   A.nlevels = L.n;
   A.prev_pts = ctx->d_prev_pts; A.next_pts = ctx->d_next_pts;
   A.status = ctx->d_status; A.err = ctx->d_err; A.npts = ctx->d_npts;

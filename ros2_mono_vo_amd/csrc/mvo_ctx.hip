@@ -106,6 +106,7 @@ static int mvo_create_impl(const mvo_config* cfg, mvo_ctx** out) {
   if (const char* e = getenv("MVO_PNP_REFINE_WAVES")) ctx->refine_waves = atoi(e) == 4 ? 4 : (atoi(e) == 1 ? 1 : 0);
   *out = ctx;
   if (cfg->device >= 0) MVO_HIP(hipSetDevice(cfg->device));
+  MVO_HIP(hipGetDevice(&ctx->device));   // the ordinal the context lives on (cfg.device = -1: the caller's current device)
   if (cfg->hip_stream) {
     ctx->stream = (hipStream_t)cfg->hip_stream;
   } else {
@@ -115,13 +116,16 @@ static int mvo_create_impl(const mvo_config* cfg, mvo_ctx** out) {
   // LK pyramids
   LkLevels L = lk_levels(ctx->maxw, ctx->maxh, 1, MVO_LK_MAX_LEVELS - 1);  // capacity: all 4 levels
   size_t off = 0;
-  for (int l = 0; l < MVO_LK_MAX_LEVELS; l++) {
+  for (int l = 1; l < MVO_LK_MAX_LEVELS; l++) {
     ctx->lk_level_off[l] = off;
     if (l < L.n) off += (size_t)L.pitch[l] * L.h[l];
     off = (off + 255) & ~(size_t)255;
   }
-  ctx->lk_slot_bytes = off;
-  for (int i = 0; i < 2; i++) MVO_HIP(hipMalloc(&ctx->lk_mem[i], ctx->lk_slot_bytes * ctx->B));
+  ctx->lk_slot_bytes = off + 256;
+  for (int i = 0; i < 2; i++) {
+    MVO_HIP(hipMalloc(&ctx->lk_mem[i], ctx->lk_slot_bytes * ctx->B));
+    MVO_HIP(hipMalloc(&ctx->lk_l0[i], (size_t)L.pitch[0] * L.h[0] + 256));
+  }
   size_t np = (size_t)ctx->B * ctx->maxpts;
   MVO_HIP(hipMalloc(&ctx->d_prev_pts, np * 2 * sizeof(float)));
   MVO_HIP(hipMalloc(&ctx->d_next_pts, np * 2 * sizeof(float)));
@@ -164,7 +168,7 @@ extern "C" void mvo_destroy(mvo_ctx* ctx) {
   geom_state_destroy(ctx);
   match_state_destroy(ctx);
   orb_state_destroy(ctx);
-  for (int i = 0; i < 2; i++) (void)hipFree(ctx->lk_mem[i]);
+  for (int i = 0; i < 2; i++) { (void)hipFree(ctx->lk_mem[i]); (void)hipFree(ctx->lk_l0[i]); }
   (void)hipFree(ctx->d_prev_pts);
   (void)hipFree(ctx->d_next_pts);
   (void)hipFree(ctx->d_status);

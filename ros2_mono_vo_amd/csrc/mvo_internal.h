@@ -41,13 +41,16 @@ struct mvo_ctx {
   void set_error(const std::string& s) { err = s; }
 
   int B = 1;       // slots
+  int device = 0;  // HIP device ordinal (resolved at create)
   int refine_waves = 0;  // PnP refine block: 0 = by batch size, 1 / 4 wavefronts forced (MVO_PNP_REFINE_WAVES, tests)
   int maxw = 0, maxh = 0, maxpts = 0;
 
   // ---- LK: two pyramid sets (ping-pong "prev"/"cur") --------------------------------------------
-  u8* lk_mem[2] = {nullptr, nullptr};   // backing store, levels packed per slot
+  u8* lk_mem[2] = {nullptr, nullptr};   // levels 1.. of every slot, packed per slot
+  u8* lk_l0[2] = {nullptr, nullptr};    // level 0 of slot 0 only: the per-call API (mvo_lk_track, mvo_pyrdown).  The frame-batch
+                                        // tracker reads level 0 in place from the frame ring and keeps no copy of it.
   size_t lk_slot_bytes = 0;
-  size_t lk_level_off[MVO_LK_MAX_LEVELS] = {0, 0, 0, 0};
+  size_t lk_level_off[MVO_LK_MAX_LEVELS] = {0, 0, 0, 0};   // [0] unused
   int lk_cur = 0;  // index of the "cur" set
   float* d_prev_pts = nullptr;  // [B][maxpts][2]
   float* d_next_pts = nullptr;
@@ -203,17 +206,14 @@ struct PipeState {
   u8* d_tri_ok = nullptr;     // [B][maxpts]
   double* d_kf_pose = nullptr;  // [B][8] T_cw of the last key-frame (rvec, tvec)
   int* d_ntri = nullptr;      // [B]
-  // side streams: the latency-bound RANSAC chains run beside ORB (they only depend on the LK survivors)
-  // s_lk carries pyramid + LK + filter (high priority: the RANSAC chains hang off it), main stream carries ORB.
-  hipStream_t s_lk = nullptr, s_pnp = nullptr, s_hf = nullptr;
-  hipEvent_t ev_frame = nullptr, ev_lktrack = nullptr, ev_lk = nullptr, ev_pnp = nullptr, ev_hf = nullptr;
-  int trk_max_n = 0;  // host-side bound on the per-slot track count (grid sizing)
-  int kf_max_n = 0;   // host-side bound on the key-frame descriptor count
+  int trk_max_n = 0;  // per-slot track count bound of the seed (informational)
+  int kf_max_n = 0;   // key-frame descriptor count bound of the seed
   struct TrackState* trk = nullptr;  // device-driven per-stream tracker (track.hip)
   // asynchronous ingest (track.hip): uploads run on their own stream; ev_up[f] = frame f of the ring has landed,
   // ev_rd[f] = the step that consumed frame f has read it (a later upload into that ring entry waits for it)
   hipStream_t s_up = nullptr;
   int step_entry = 0;       // ring entry mvo_tracker_step used last (the seed frame is entry 0)
+  int prev_entry = -1;      // ring entry of the frame seeded / tracked last: it IS level 0 of the "prev" LK pyramid (read in place)
   bool up_shared = false;   // uploads ride on the compute stream (MVO_UPLOAD_STREAM=0)
   std::vector<hipEvent_t> ev_up, ev_rd;
   std::vector<char> up_pending, rd_pending;
@@ -244,9 +244,11 @@ int trk_sync_upload(mvo_ctx* ctx);                  // host waits for the upload
 void lk_filter_compact_launch(mvo_ctx* ctx, hipStream_t st);   // pipeline.hip: status/err filter of all slots
 
 // device-level stage drivers (all slots per launch)
-int lk_build_pyramid(mvo_ctx* ctx, int set, const LkLevels& L, int nslots, hipStream_t st = nullptr);
+int lk_build_pyramid(mvo_ctx* ctx, int set, const LkLevels& L, int nslots, hipStream_t st = nullptr, const u8* l0 = nullptr,
+                     size_t l0_stride = 0);
 int lk_track_device(mvo_ctx* ctx, int prev_set, int cur_set, const LkLevels& L, int nslots, int max_n, hipStream_t st = nullptr,
-                    const int* d_work_slot = nullptr, const int* d_pt_base = nullptr, int* d_work_ctr = nullptr);
+                    const int* d_work_slot = nullptr, const int* d_pt_base = nullptr, int* d_work_ctr = nullptr,
+                    const u8* prev_l0 = nullptr, const u8* cur_l0 = nullptr, size_t l0_stride = 0);
 // ORB in three phases on ctx->stream so that a caller can put other GPU work beside the host-side selection:
 //   orb_detect_enqueue  pyramid, FAST+NMS, ordered compaction, async copy of the counts           (no host wait)
 //   orb_select          waits for the counts (capacity check, grid size), Harris, OpenCV's two retainBest passes per

@@ -63,7 +63,7 @@ struct TrackState {
 // context that was (process-wide, one process per GPU).  MVO_LK_TURNS=0 turns the ordering off.
 static std::mutex g_lk_mu;
 static hipEvent_t g_lk_last_dev[32] = {};   // per device: a process that drives several GPUs orders each one's launches separately
-static hipEvent_t& lk_last(const mvo_ctx* ctx) { return g_lk_last_dev[(unsigned)ctx->cfg.device % 32u]; }
+static hipEvent_t& lk_last(const mvo_ctx* ctx) { return g_lk_last_dev[(unsigned)ctx->device % 32u]; }   // ordinal resolved by mvo_create
 static bool lk_turns() {
   static const bool on = !(getenv("MVO_LK_TURNS") && atoi(getenv("MVO_LK_TURNS")) == 0);
   return on;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(1024) void trk_worklist_scan_kernel(const int* __re
     int v = 0;
     if (s < B) {
       v = state[s] == MVO_TRACK_TRACKING ? min(max(npts[s], 0), maxpts) : 0;
-      npts[s] = v;        // a LOST / ABORTED stream feeds nothing to LK (Tracker::update returns at once)
+      npts[s] = v;        // a LOST stream feeds nothing to LK (Tracker::update returns at once)
       flags[s] = 0;
       mvo_step_result z;
       memset(&z, 0, sizeof(z));
@@ -127,16 +127,6 @@ __global__ __launch_bounds__(256) void trk_worklist_expand_kernel(const int* __r
   for (int i = b + threadIdx.x; i < e; i += 256) work_slot[i] = s;
 }
 
-// LK level 0 of the "cur" pyramid set <- ring frame (all slots; 16 B per lane)
-__global__ __launch_bounds__(256) void trk_ring_to_lk0_kernel(const u8* __restrict__ ring, size_t ring_slot_stride, int pitch, int h,
-                                                              u8* __restrict__ lk0, size_t lk_slot_stride) {
-  const int slot = blockIdx.y;
-  const size_t n16 = (size_t)pitch * h / 16;
-  const uint4* s = (const uint4*)(ring + (size_t)slot * ring_slot_stride);
-  uint4* a = (uint4*)(lk0 + (size_t)slot * lk_slot_stride);
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) a[i] = s[i];
-}
-
 // After the status/err filter: min_tracked_points -> LOST (src/tracker.cpp:292-296); the others go on to PnP.
 __global__ __launch_bounds__(256) void trk_policy_lost_kernel(int* __restrict__ state, const int* __restrict__ ncur, int B,
                                                               long long min_tracked, int* __restrict__ n_pnp, int* __restrict__ flags,
@@ -168,8 +158,9 @@ __device__ inline void trk_rodrigues(const double r_[3], double R[9]) {   // cal
 }
 
 // After PnP: pose, ++tracking_count_from_keyframe_, should_add_keyframe (src/tracker.cpp:318-319, 118-136, 92-116).
-// The reference does not look at solvePnPRansac's return value: on failure rvec stays empty and cv::Rodrigues throws out
-// of image_callback.  Here the stream goes to MVO_TRACK_ABORTED (terminal, no pose) instead of taking the process down.
+// The reference does not look at solvePnPRansac's return value; without a model its pose for the frame is whatever an
+// uninitialised 3x1 Mat holds (include/mvo.h, MVO_STEP_PNP_FAILED).  Defined here: no pose for the frame, the count still
+// advances, no key-frame test, the stream keeps tracking (trk_finalize_kernel carries the LK survivors forward).
 __global__ __launch_bounds__(256) void trk_policy_keyframe_kernel(int* __restrict__ state, int* __restrict__ count, int B,
                                                                   const int* __restrict__ n_pnp, const int* __restrict__ pnp_result,
                                                                   const double* __restrict__ pose, const double* __restrict__ kf_pose,
@@ -185,8 +176,8 @@ __global__ __launch_bounds__(256) void trk_policy_keyframe_kernel(int* __restric
     res[s].pnp_ok = ok;
     res[s].n_pnp_inliers = pnp_result[8 * s + 5];
     if (!ok) {
-      state[s] = MVO_TRACK_ABORTED;
-      flags[s] |= MVO_STEP_ABORTED_NOW;
+      flags[s] |= MVO_STEP_PNP_FAILED;
+      count[s] = count[s] + 1;
     } else {
       const double* p = pose + 8 * s;
       for (int k = 0; k < 3; k++) { res[s].rvec[k] = p[k]; res[s].tvec[k] = p[3 + k]; }
@@ -266,7 +257,7 @@ __global__ __launch_bounds__(1024) void trk_policy_parallax_kernel(const int* __
   if (threadIdx.x == 0) *nkf = s_base;
 }
 
-// ORB level 0 of compact ORB slot j <- LK "cur" level 0 of stream slot kf_list[j] (same image, same pitch)
+// ORB level 0 of compact ORB slot j <- the ring frame of stream slot kf_list[j] (same image, same pitch)
 __global__ __launch_bounds__(256) void trk_gather_orb0_kernel(const u8* __restrict__ lk0, size_t lk_slot_stride, int pitch, int h,
                                                               u8* __restrict__ orb0, size_t orb_slot_stride,
                                                               const int* __restrict__ kf_list, const int* __restrict__ nkf, int chunks) {
@@ -405,15 +396,13 @@ __device__ inline void trk_pose_cw_to_ros(const double* pose_cw /* rvec, tvec */
 
 // The pose bookkeeping of MonoVO::image_callback (src/mono_vo.cpp:119-148) for every slot after its Tracker::update: LOST ->
 // tracking_valid_ = false and the last pose is kept; a returned pose becomes last_pose_ (tracking_valid_ = true); while
-// tracking is valid one PoseStamped goes onto the path.  An ABORTED slot (the reference process would have died in
-// cv::Rodrigues) is frozen: no update, no path entry.
+// tracking is valid one PoseStamped goes onto the path (a frame without a pose repeats the last one, as there).
 __global__ __launch_bounds__(256) void trk_output_kernel(const int* __restrict__ state, const int* __restrict__ flags, const double* __restrict__ pose,
                                                          int B, mvo_ros_pose* __restrict__ ros, double* __restrict__ path, int* __restrict__ n_path,
                                                          int path_cap, int* __restrict__ err) {
   const int s = blockIdx.x * 256 + threadIdx.x;
   if (s >= B) return;
   const int st = state[s];
-  if (st == MVO_TRACK_ABORTED) return;
   mvo_ros_pose r = ros[s];
   if (st == MVO_TRACK_LOST) r.tracking_valid = 0;
   else if (flags[s] & MVO_STEP_POSE) {
@@ -555,7 +544,7 @@ __global__ __launch_bounds__(256) void trk_finalize_kernel(const int* __restrict
   const int slot = blockIdx.x;
   const int f = flags[slot], st = state[slot];
   const size_t b = (size_t)slot * maxpts;
-  if (st == MVO_TRACK_TRACKING && (f & MVO_STEP_POSE) && !(f & MVO_STEP_KEYFRAME)) {
+  if (st == MVO_TRACK_TRACKING && (f & (MVO_STEP_POSE | MVO_STEP_PNP_FAILED)) && !(f & MVO_STEP_KEYFRAME)) {
     const int n = min(max(ncur[slot], 0), maxpts);
     for (int i = threadIdx.x; i < 2 * n; i += 256) { trk_xy[2 * b + i] = cur_pts[2 * b + i]; trk_kf[2 * b + i] = cur_kf[2 * b + i]; }
     for (int i = threadIdx.x; i < 3 * n; i += 256) trk_lm[3 * b + i] = cur_lm[3 * b + i];
@@ -685,9 +674,11 @@ extern "C" int mvo_batch_upload_async(mvo_ctx* ctx, int frame_idx, const uint8_t
   int rc = trk_ring_events(ctx);
   if (rc) return rc;
   if (p->rd_pending[frame_idx]) { MVO_HIP(hipStreamWaitEvent(p->s_up, p->ev_rd[frame_idx], 0)); p->rd_pending[frame_idx] = 0; }
+  if (frame_idx == p->prev_entry) p->prev_entry = -1;   // the previous frame's image is gone: the next step must be a seed (see mvo_batch_track_async)
   u8* dst = p->d_ring + (size_t)frame_idx * ctx->B * p->frame_bytes;
   if (stride == p->pitch && slot_stride == p->frame_bytes) {
-    MVO_HIP(hipMemcpyAsync(dst, frames, p->frame_bytes * ctx->B, hipMemcpyDefault, p->s_up));
+    // one linear copy; the last slot stops at its last pixel (the caller guarantees no more than that to be readable)
+    MVO_HIP(hipMemcpyAsync(dst, frames, p->frame_bytes * (ctx->B - 1) + (size_t)stride * (h - 1) + w, hipMemcpyDefault, p->s_up));
   } else if (slot_stride == (size_t)stride * h) {
     // one 2-D copy: the B images are one tall image of B*h rows on the host; on the device the slots are frame_bytes
     // = pitch * maxh apart, which equals pitch * h only when h == maxh
@@ -709,36 +700,33 @@ extern "C" int mvo_batch_upload_async(mvo_ctx* ctx, int frame_idx, const uint8_t
 }
 
 // Enqueue one tracker step of every slot on ring frame `frame_idx`; returns without waiting for the device.
-extern "C" int mvo_batch_track_async(mvo_ctx* ctx, int frame_idx) {
-  if (!ctx || !ctx->pipe) return MVO_E_ARG;
+//
+// Level 0 of both LK pyramids is read IN PLACE from the frame ring: "prev" is the entry tracked (or seeded) last, "cur" is
+// `frame_idx`; only levels 1.. are built (pyramid sets, ping-pong).  The entry of the previous frame therefore has to stay
+// intact until this step's LK launch has run: ev_rd[prev] is recorded right after it, and an asynchronous upload into that
+// entry waits for it.  A 2-entry ring works (the upload of frame k+1 overlaps everything of step k behind its LK launch), a
+// 3-entry ring overlaps the upload with the whole step.
+static int trk_step_enqueue(mvo_ctx* ctx, int frame_idx) {
   PipeState* p = ctx->pipe;
   MatchState* m = ctx->match;
   GeomState* g = ctx->geom;
   OrbState* o = ctx->orb;
-  if (!p->seeded || frame_idx < 0 || frame_idx >= p->ring) { ctx->set_error("mvo_batch_track: not seeded / bad frame"); return MVO_E_ARG; }
-  int rc = trk_create(ctx);
-  if (rc) return rc;
   TrackState* t = p->trk;
-  if (t->pending) { ctx->set_error("mvo_batch_track_async: the previous step has not been collected (mvo_batch_track_wait)"); return MVO_E_ARG; }
-  if ((rc = trk_ring_events(ctx))) return rc;
+  int rc;
   const int B = ctx->B, cap = ctx->maxpts;
   hipStream_t st = ctx->stream;
   const mvo_config& c = ctx->cfg;
   LkLevels L = lk_levels(p->w, p->h, c.lk_win, c.lk_max_level);
   const int prev_set = ctx->lk_cur, cur_set = ctx->lk_cur ^ 1;
   const int nb = (B + 255) / 256;
+  const int prev_entry = p->prev_entry;
+  const size_t entry_bytes = (size_t)B * p->frame_bytes;
+  const u8* ring_prev = p->d_ring + (size_t)prev_entry * entry_bytes;
+  const u8* ring_cur = p->d_ring + (size_t)frame_idx * entry_bytes;
 
   if ((rc = trk_wait_upload(ctx, frame_idx))) return rc;
-  // ---- LK: frame -> "cur" pyramid; dense work list over the slots that are tracking ----------------------------------
-  {
-    ProfScope ps(ctx, "frame_fanout");
-    const u8* src = p->d_ring + (size_t)frame_idx * B * p->frame_bytes;
-    hipLaunchKernelGGL(trk_ring_to_lk0_kernel, dim3(64, B), dim3(256), 0, st, src, p->frame_bytes, p->pitch, p->h,
-                       ctx->lk_mem[cur_set] + ctx->lk_level_off[0], ctx->lk_slot_bytes);
-  }
-  MVO_HIP(hipEventRecord(p->ev_rd[frame_idx], st));   // the ring entry may be overwritten from here on
-  p->rd_pending[frame_idx] = 1;
-  { ProfScope ps(ctx, "lk_pyramid"); lk_build_pyramid(ctx, cur_set, L, B, st); }
+  // ---- LK: levels 1.. of the "cur" pyramid from the ring entry; dense work list over the slots that are tracking -------
+  { ProfScope ps(ctx, "lk_pyramid"); lk_build_pyramid(ctx, cur_set, L, B, st, ring_cur, p->frame_bytes); }
   {
     ProfScope ps(ctx, "lk_worklist");
     hipLaunchKernelGGL(trk_worklist_scan_kernel, dim3(1), dim3(1024), 0, st, t->d_state, ctx->d_npts, B, cap, t->d_pt_base, t->d_work_ctr,
@@ -749,13 +737,16 @@ extern "C" int mvo_batch_track_async(mvo_ctx* ctx, int frame_idx) {
     std::lock_guard<std::mutex> lock(g_lk_mu);
     hipEvent_t& last = lk_last(ctx);
     if (last && last != t->ev_lk) MVO_HIP(hipStreamWaitEvent(st, last, 0));
-    { ProfScope ps(ctx, "lk_track"); lk_track_device(ctx, prev_set, cur_set, L, B, cap, st, t->d_work_slot, t->d_pt_base, t->d_work_ctr); }
+    { ProfScope ps(ctx, "lk_track");
+      lk_track_device(ctx, prev_set, cur_set, L, B, cap, st, t->d_work_slot, t->d_pt_base, t->d_work_ctr, ring_prev, ring_cur, p->frame_bytes); }
     MVO_HIP(hipEventRecord(t->ev_lk, st));
     last = t->ev_lk;
   } else {
     ProfScope ps(ctx, "lk_track");
-    lk_track_device(ctx, prev_set, cur_set, L, B, cap, st, t->d_work_slot, t->d_pt_base, t->d_work_ctr);
+    lk_track_device(ctx, prev_set, cur_set, L, B, cap, st, t->d_work_slot, t->d_pt_base, t->d_work_ctr, ring_prev, ring_cur, p->frame_bytes);
   }
+  MVO_HIP(hipEventRecord(p->ev_rd[prev_entry], st));   // the previous frame's ring entry may be overwritten from here on
+  p->rd_pending[prev_entry] = 1;
   {
     ProfScope ps(ctx, "lk_filter");
     lk_filter_compact_launch(ctx, st);
@@ -782,9 +773,8 @@ extern "C" int mvo_batch_track_async(mvo_ctx* ctx, int frame_idx) {
   {
     ProfScope ps(ctx, "kf_gather");
     const int chunks = 16;
-    hipLaunchKernelGGL(trk_gather_orb0_kernel, dim3(persist_grid((unsigned)B * chunks)), dim3(256), 0, st,
-                       ctx->lk_mem[cur_set] + ctx->lk_level_off[0], ctx->lk_slot_bytes, p->pitch, p->h, o->d_pyr, o->slot_bytes,
-                       t->d_kf_list, t->d_nkf, chunks);
+    hipLaunchKernelGGL(trk_gather_orb0_kernel, dim3(persist_grid((unsigned)B * chunks)), dim3(256), 0, st, ring_cur, p->frame_bytes, p->pitch,
+                       p->h, o->d_pyr, o->slot_bytes, t->d_kf_list, t->d_nkf, chunks);
   }
   if ((rc = orb_run_device(ctx, p->w, p->h, B, t->d_nkf))) return rc;
   {
@@ -816,9 +806,43 @@ extern "C" int mvo_batch_track_async(mvo_ctx* ctx, int frame_idx) {
   MVO_HIP(hipMemcpyAsync(t->h_res, t->d_res, (size_t)B * sizeof(mvo_step_result), hipMemcpyDeviceToHost, st));
   MVO_HIP(hipMemcpyAsync(t->h_err, t->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
   MVO_HIP(hipEventRecord(t->ev_done, st));
-  ctx->lk_cur = cur_set;
-  p->trk_max_n = cap;   // the stage-mask step (mvo_batch_step) sizes its LK grid from this bound
-  p->kf_max_n = cap;
+  // this step's own reads of its frame (the key-frame branch's gather) are over at ev_rd[frame_idx]; the next step's LK launch
+  // re-records it, since the entry is then the "prev" image
+  MVO_HIP(hipEventRecord(p->ev_rd[frame_idx], st));
+  p->rd_pending[frame_idx] = 1;
+  return MVO_OK;
+}
+
+extern "C" int mvo_batch_track_async(mvo_ctx* ctx, int frame_idx) {
+  if (!ctx || !ctx->pipe) return MVO_E_ARG;
+  PipeState* p = ctx->pipe;
+  if (!p->seeded || frame_idx < 0 || frame_idx >= p->ring) { ctx->set_error("mvo_batch_track: not seeded / bad frame"); return MVO_E_ARG; }
+  int rc = trk_create(ctx);
+  if (rc) return rc;
+  TrackState* t = p->trk;
+  if (t->pending) { ctx->set_error("mvo_batch_track_async: the previous step has not been collected (mvo_batch_track_wait)"); return MVO_E_ARG; }
+  if ((rc = trk_ring_events(ctx))) return rc;
+  if (p->prev_entry < 0) {
+    ctx->set_error("mvo_batch_track: the ring entry of the previous frame was overwritten before the next step (it is level 0 of the LK "
+                   "template): keep it until the following step has been enqueued, or seed again");
+    return MVO_E_ARG;
+  }
+  if (frame_idx == p->prev_entry) {
+    ctx->set_error("mvo_batch_track: frame_idx is the ring entry of the previous frame (ring_frames >= 2: put the new frame into another entry)");
+    return MVO_E_ARG;
+  }
+  rc = trk_step_enqueue(ctx, frame_idx);
+  if (rc != MVO_OK) {
+    // half a step is queued: drain it and refuse further steps until the caller seeds again (the per-stream state is undefined)
+    const std::string why = ctx->err;
+    (void)hipStreamSynchronize(ctx->stream);
+    p->seeded = false;
+    p->prev_entry = -1;
+    ctx->set_error("mvo_batch_track_async failed mid-step (" + why + "); the tracker state is void: seed again");
+    return rc;
+  }
+  ctx->lk_cur ^= 1;
+  p->prev_entry = frame_idx;
   t->pending = true;
   return MVO_OK;
 }
@@ -988,12 +1012,19 @@ int trk_sync_upload(mvo_ctx* ctx) {
   return MVO_OK;
 }
 
-// Called by mvo_batch_seed: every slot starts TRACKING with tracking_count_from_keyframe_ = 0.
+// Called by mvo_batch_seed: a step still in flight finishes first (its results are dropped); every slot starts TRACKING with
+// tracking_count_from_keyframe_ = 0, no capacity flags, and an empty path (the cloud restarts with mvo_batch_set_landmarks).
 int trk_reset(mvo_ctx* ctx) {
   if (!ctx->pipe || !ctx->pipe->trk) return MVO_OK;
   TrackState* t = ctx->pipe->trk;
+  if (t->pending) { MVO_HIP(hipEventSynchronize(t->ev_done)); t->pending = false; }
   MVO_HIP(hipMemsetAsync(t->d_state, 0, ctx->B * sizeof(int), ctx->stream));
   MVO_HIP(hipMemsetAsync(t->d_count, 0, ctx->B * sizeof(int), ctx->stream));
-  t->pending = false;
+  MVO_HIP(hipMemsetAsync(t->d_err, 0, sizeof(int), ctx->stream));
+  if (t->out_on) {
+    MVO_HIP(hipMemsetAsync(t->d_n_cloud, 0, ctx->B * sizeof(int), ctx->stream));
+    MVO_HIP(hipMemsetAsync(t->d_n_path, 0, ctx->B * sizeof(int), ctx->stream));
+    MVO_HIP(hipMemsetAsync(t->d_ros, 0, ctx->B * sizeof(mvo_ros_pose), ctx->stream));
+  }
   return MVO_OK;
 }

@@ -352,12 +352,6 @@ class TrackerState(enum.Enum):
     LOST = 2
 
 
-class ReferenceAbort(RuntimeError):
-    """A cv::Exception the reference does not catch.  Raised where solvePnPRansac finds no model: rvec_cw stays an empty
-    Mat and cv::Rodrigues (src/tracker.cpp:315) throws out of MonoVO::image_callback (only cv_bridge's exception is caught,
-    src/mono_vo.cpp:93-98).  The frame-batch tracker reports the same event as MVO_TRACK_ABORTED for that stream."""
-
-
 class Tracker:
     """src/tracker.cpp — per-frame tracking."""
 
@@ -474,7 +468,12 @@ class Tracker:
         ok, rvec, tvec, inliers = self.backend.solve_pnp_ransac(p3, p2, K, d, 100, 8.0, 0.99)
         self.last.update(pnp_ok=ok, n_pnp_inliers=len(inliers), rvec=rvec, tvec=tvec)
         if not ok:
-            raise ReferenceAbort("solvePnPRansac found no model: cv::Rodrigues on an empty rvec")
+            # The reference ignores the return value (src/tracker.cpp:309-315): OpenCV creates rvec / tvec before RANSAC and,
+            # without a model, assigns them from an uninitialised Mat - its pose for this frame is undefined.  Defined here
+            # (include/mvo.h, MVO_STEP_PNP_FAILED): no pose, the count advances, no key-frame test, the survivors carry on.
+            self.tracking_count_from_keyframe += 1
+            self.prev_frame = new_frame
+            return None
         R_cw = rodrigues_vec_to_mat(rvec)
         new_frame.pose_wc = affine_inv(affine(R_cw, tvec))
         self.tracking_count_from_keyframe += 1

@@ -1,5 +1,5 @@
 """Oracle-driven restatement of the frame-batch step (csrc/pipeline.hip) for one camera stream — TEST
-INFRASTRUCTURE ONLY.  Same data flow as mvo_batch_step with MVO_STAGE_ALL, every stage computed by the
+INFRASTRUCTURE ONLY.  Same data flow as mvo_batch_track under policy 1 (key-frame branch on every tracked frame), every stage computed by the
 CPU oracle: used by tests/test_gpu_pipeline.py as the end-to-end checker and by bench.py's cpu_baseline leg.
 
 The flow is the reference's steady-state Tracker::update (src/tracker.cpp:274-333) with the key-frame

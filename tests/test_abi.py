@@ -18,7 +18,7 @@ def test_header_declares_the_boundary():
     syms = declared_symbols()
     for must in ("mvo_create", "mvo_orb_detect_and_compute", "mvo_match_knn2_ratio", "mvo_lk_track",
                  "mvo_find_homography_ransac", "mvo_find_fundamental_ransac", "mvo_solve_pnp_ransac",
-                 "mvo_find_essential_ransac", "mvo_recover_pose", "mvo_triangulate", "mvo_batch_step"):
+                 "mvo_find_essential_ransac", "mvo_recover_pose", "mvo_triangulate", "mvo_batch_track"):
         assert must in syms
 
 

@@ -1,5 +1,6 @@
-"""End-to-end parity of the fused frame-batch step (mvo_batch_step, all stages, B independent streams in
-one launch per stage) against the same data flow computed by the CPU oracle (tests/pipeline_ref.py).
+"""End-to-end parity of the frame-batch step with the key-frame branch forced on every frame (mvo_batch_track under policy 1:
+every stage runs for every slot, B independent streams in one launch per stage) against the same data flow computed by the
+CPU oracle (tests/pipeline_ref.py).
 Integer results (track / key-point / match / inlier / triangulation counts, H and F scores) must be
 identical; the PnP pose must agree to 1e-6 (contract: 1e-4) — the LM sums are block reductions on the GPU."""
 import numpy as np
@@ -37,8 +38,9 @@ def test_batch_step_matches_oracle_flow(B, W, H):
             assert np.array_equal(trk, r.trk_xy)
             ctx.batch_set_landmarks(s, r.trk_lm)
             refs.append(r)
+        ctx.batch_set_policy(1)
         for k in range(1, STEPS + 1):
-            out = ctx.batch_step(k, _lib.STAGE_ALL)
+            out = ctx.batch_track(k)
             for s in range(B):
                 o, e = out[s], refs[s].step(streams[s][k])
                 for key in ("n_prev", "n_tracked", "n_keypoints", "n_matches", "n_pnp_inliers", "score_h", "score_f",
@@ -48,9 +50,15 @@ def test_batch_step_matches_oracle_flow(B, W, H):
                 assert np.abs(np.array(o.rvec) - e["rvec"]).max() < 1e-6
                 assert np.abs(np.array(o.tvec) - e["tvec"]).max() < 1e-6 * max(1.0, np.abs(e["tvec"]).max())
                 assert o.n_tracked > 300 and o.n_pnp_inliers > 0.8 * o.n_tracked
-        # stage subsets: LK only keeps the survivors as tracks
-        out = ctx.batch_step(STEPS, _lib.STAGE_LK)
-        assert all(out[s].n_prev > 0 for s in range(B))
+                assert o.flags == _lib.STEP_POSE | _lib.STEP_KF_CHECKED | _lib.STEP_KEYFRAME and o.n_tracks == e["n_new_tracks"]
+        # the ring entry of the frame tracked last is the LK template of the next step: tracking it again is refused ...
+        with pytest.raises(RuntimeError):
+            ctx.batch_track(STEPS)
+        # ... and overwriting it voids the tracker until it is seeded again
+        ctx.batch_preload_frame(0, STEPS, streams[0][STEPS])
+        with pytest.raises(RuntimeError):
+            ctx.batch_track(0)
+        assert ctx.batch_seed(0)[0] == nk[0]
 
 
 def test_batch_with_empty_and_lost_streams():
@@ -77,8 +85,9 @@ def test_batch_with_empty_and_lost_streams():
         ref.seed(good[0], planar_landmarks(K))
         for s in (0, 2):
             ctx.batch_set_landmarks(s, ref.trk_lm)
+        ctx.batch_set_policy(1)
         for k in range(1, STEPS + 1):
-            out = ctx.batch_step(k, _lib.STAGE_ALL)
+            out = ctx.batch_track(k)
             e = ref.step(good[k])
             o = out[0]
             for key in ("n_prev", "n_tracked", "n_keypoints", "n_matches", "n_pnp_inliers", "score_h", "score_f", "n_triangulated"):
@@ -110,11 +119,12 @@ def test_two_slot_ring_matches_preloaded_ring():
             ctx.batch_seed(0)
             for s in range(B):
                 ctx.batch_set_landmarks(s, planar_landmarks(K)(ctx.batch_get_tracks(s)))
+            ctx.batch_set_policy(1)
             for k in range(1, STEPS + 1):
                 slot = k % ring
                 for s in range(B):
                     ctx.batch_preload_frame(s, slot, streams[s][k])
-                out = ctx.batch_step(slot, _lib.STAGE_ALL)
+                out = ctx.batch_track(slot)
                 outs.append([(o.n_tracked, o.n_keypoints, o.n_matches, o.n_pnp_inliers, o.score_h, o.score_f, o.n_triangulated,
                               tuple(o.rvec), tuple(o.tvec)) for o in out])
         return outs

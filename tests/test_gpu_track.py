@@ -78,7 +78,7 @@ def test_heterogeneous_streams_take_their_own_branches():
 def test_forced_keyframe_policy_at_benchmark_sizes(B, W, H, NF, STEPS):
     """The worst-case load bench.py can select (policy 1: key-frame branch on every tracked frame) at the sizes it is
     quoted on - C3 1280x720 / 2000 features with 4 DISTINCT streams, C4 1920x1080 / 4000 - against the oracle flow
-    (tests/pipeline_ref.py), through the device-driven step and through the stage-mask step."""
+    (tests/pipeline_ref.py)."""
     K = synth.default_K(W, H)
     streams = [synth.gen_stream(W, H, 0x5EED0500 + 7 * s, STEPS + 1) for s in range(B)]
     refs = []
@@ -87,7 +87,7 @@ def test_forced_keyframe_policy_at_benchmark_sizes(B, W, H, NF, STEPS):
         r.seed(streams[s][0], planar_landmarks(K))
         refs.append(r)
     exp = [[refs[s].step(streams[s][k]) for s in range(B)] for k in range(1, STEPS + 1)]
-    for mode in ("track", "stage_mask"):
+    for mode in ("track",):
         with Context(max_width=W, max_height=H, batch=B, nfeatures=NF, max_points=8192 if NF > 2000 else 4096, ring_frames=STEPS + 1) as ctx:
             ctx.batch_set_intrinsics(K)
             for s in range(B):
@@ -99,7 +99,7 @@ def test_forced_keyframe_policy_at_benchmark_sizes(B, W, H, NF, STEPS):
             if mode == "track":
                 ctx.batch_set_policy(1)
             for k in range(1, STEPS + 1):
-                out = ctx.batch_track(k) if mode == "track" else ctx.batch_step(k, _lib.STAGE_ALL)
+                out = ctx.batch_track(k)
                 for s in range(B):
                     o, e = out[s], exp[k - 1][s]
                     for key in ("n_prev", "n_tracked", "n_keypoints", "n_matches", "n_pnp_inliers", "score_h", "score_f", "n_triangulated"):
@@ -312,3 +312,63 @@ def test_output_side_capacity_and_misuse():
         assert ei.value.code == _lib.MVO_E_CAPACITY and len(ctx.batch_get_path(0)) == 2
         st, _ = ctx.batch_get_state()
         assert st[0] == _lib.TRACK_TRACKING                  # the tracker itself is unaffected
+
+
+def garbage_landmarks(n, seed=5):
+    """Landmarks unrelated to the image: solvePnPRansac finds no model on them (checked on the oracle side of the test)."""
+    rng = np.random.default_rng(seed)
+    return np.stack([rng.uniform(-40, 40, n), rng.uniform(-40, 40, n), rng.uniform(-30, 60, n)], 1).astype(np.float32)
+
+
+def relocate_landmarks(ref, lm):
+    """The reference side of mvo_batch_set_landmarks on a running stream: new positions for the current tracks' landmarks."""
+    ids = ref.tracker.prev_frame.landmark_id
+    ids = ids[ids != -1]
+    assert len(ids) == len(lm)
+    for i, l in enumerate(ids):
+        ref.map.landmarks[int(l)].pose_w = np.asarray(lm[i], np.float32).copy()
+
+
+def test_pnp_failure_is_a_frame_without_pose_and_the_stream_recovers():
+    """solvePnPRansac without a model (include/mvo.h, MVO_STEP_PNP_FAILED): the reference's pose for such a frame is undefined
+    (uninitialised rvec); defined here as NO pose, stream still TRACKING, tracking_count + 1, LK survivors carried forward, so
+    the next frame can recover.  Slot 0 is seeded with landmarks that fit no pose (PnP fails on frame 1), gets consistent ones
+    before frame 2 and must then deliver poses again; slot 1 is healthy throughout.  Both against the reference tracker over
+    the oracle with the same landmark edits."""
+    N, NF = 5, 1000
+    K = synth.default_K(TS.W, TS.H)
+    fr, d0 = TS.stream("lateral", N)
+    with Context(max_width=TS.W, max_height=TS.H, batch=2, nfeatures=NF, max_points=4096, ring_frames=N) as ctx:
+        ctx.batch_set_intrinsics(K)
+        ctx.batch_enable_output(map_capacity=8192, path_capacity=16)
+        for s in range(2):
+            for f in range(N):
+                ctx.batch_preload_frame(s, f, fr[f])
+        nk = ctx.batch_seed(0)
+        refs = [TrackRef(K, NF), TrackRef(K, NF)]
+        n, xy, _ = refs[0].seed(fr[0], lambda p: garbage_landmarks(len(p)))
+        ctx.batch_set_landmarks(0, garbage_landmarks(n))
+        n1, xy1, lm1 = refs[1].seed(fr[0], TS.depth_landmarks(K, d0))
+        ctx.batch_set_landmarks(1, lm1)
+        assert n == nk[0] and n1 == nk[1]
+        for k in range(1, N):
+            out = ctx.batch_track(k)
+            exp = [r.step(fr[k]) for r in refs]
+            for s in range(2):
+                check(out[s], exp[s], (k, s))
+            o = out[0]
+            if k == 1:
+                assert exp[0]["flags"] == _lib.STEP_PNP_FAILED, "the scenario must make the oracle's PnP fail too"
+                assert o.state == _lib.TRACK_TRACKING and o.tracking_count == 1 and o.n_tracks == o.n_tracked > 300 and not o.pnp_ok
+                odo = ctx.batch_get_odometry()[0]
+                assert odo.tracking_valid == 1 and list(odo.position) == [0.0, 0.0, 0.0]      # the hand-over pose is kept
+                assert len(ctx.batch_get_path(0)) == 1                                         # ... and repeated on the path
+                # consistent landmarks for the survivors: the plane z = 10 seen from the current frame
+                trk = ctx.batch_get_tracks(0)
+                lm = planar_landmarks(K)(trk)
+                ctx.batch_set_landmarks(0, lm)
+                relocate_landmarks(refs[0], lm)
+            else:
+                assert o.flags & _lib.STEP_POSE and o.pnp_ok and o.tracking_count == k and o.n_pnp_inliers > 0.5 * o.n_tracked
+        st, cnt = ctx.batch_get_state()
+        assert list(st) == [_lib.TRACK_TRACKING] * 2 and list(cnt) == [N - 1, N - 1]

@@ -18,7 +18,6 @@ class TrackRef:
         self.map = vo.Map()
         self.fp = vo.FeatureProcessor(self.backend, nfeatures)
         self.tracker = vo.Tracker(self.map, self.fp, params)
-        self.aborted = False
 
     def seed(self, img, landmarks_fn):
         f = vo.Frame(img)
@@ -36,8 +35,6 @@ class TrackRef:
         return len(xy), xy, lm
 
     def state_code(self):
-        if self.aborted:
-            return _lib.TRACK_ABORTED
         return _lib.TRACK_LOST if self.tracker.state == vo.TrackerState.LOST else _lib.TRACK_TRACKING
 
     def step(self, img):
@@ -45,23 +42,20 @@ class TrackRef:
         t = self.tracker
         r = dict(n_prev=0, n_tracked=0, pnp_ok=0, n_pnp_inliers=0, rvec=np.zeros(3), tvec=np.zeros(3), score_h=0, score_f=0,
                  n_keypoints=0, n_matches=0, n_triangulated=0, flags=0)
-        if self.aborted or t.state == vo.TrackerState.LOST:
+        if t.state == vo.TrackerState.LOST:
             r.update(state=self.state_code(), tracking_count=t.tracking_count_from_keyframe, n_tracks=0)
             return r
         r["n_prev"] = int((t.prev_frame.landmark_id != -1).sum())
         t.last = {}
-        try:
-            pose = t.update(vo.Frame(img), self.K, self.d)
-        except vo.ReferenceAbort:
-            self.aborted = True
-            pose = None
-            r["flags"] |= _lib.STEP_ABORTED_NOW
+        pose = t.update(vo.Frame(img), self.K, self.d)
         L = t.last
         r["n_tracked"] = L.get("n_tracked", 0)
         if t.state == vo.TrackerState.LOST:
             r["flags"] |= _lib.STEP_LOST_NOW
         if "pnp_ok" in L:
             r["pnp_ok"], r["n_pnp_inliers"] = int(bool(L["pnp_ok"])), L["n_pnp_inliers"]
+            if not L["pnp_ok"]:
+                r["flags"] |= _lib.STEP_PNP_FAILED
         if pose is not None:
             r["flags"] |= _lib.STEP_POSE
             r["rvec"], r["tvec"] = np.asarray(L["rvec"], np.float64), np.asarray(L["tvec"], np.float64)
@@ -71,7 +65,7 @@ class TrackRef:
         if "n_keypoints" in L:
             r["flags"] |= _lib.STEP_KEYFRAME
             r["n_keypoints"], r["n_matches"], r["n_triangulated"] = L["n_keypoints"], L["n_matches"], L["n_triangulated"]
-        alive = not self.aborted and t.state == vo.TrackerState.TRACKING
+        alive = t.state == vo.TrackerState.TRACKING
         r.update(state=self.state_code(), tracking_count=t.tracking_count_from_keyframe,
                  n_tracks=int((t.prev_frame.landmark_id != -1).sum()) if alive else 0)
         return r

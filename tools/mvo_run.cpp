@@ -110,9 +110,6 @@ int main(int argc, char** argv) {
   } catch (const mono_vo::Error& e) {
     std::fprintf(stderr, "mvo error %d: %s\n", e.code, e.what());
     return 1;
-  } catch (const mono_vo::ReferenceAbort& e) {
-    std::fprintf(stderr, "reference abort: %s\n", e.what());
-    return 3;
   }
   std::fclose(f);
   return 0;
