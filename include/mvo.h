@@ -128,6 +128,11 @@ int mvo_lk_track(mvo_ctx* ctx, const uint8_t* prev, const uint8_t* next, int w, 
                  int channels, const float* prev_pts, int n, float* next_pts, uint8_t* status, float* err);
 /* cv::pyrDown building block (parity tests). dst is ((w+1)/2) x ((h+1)/2). */
 int mvo_pyrdown(mvo_ctx* ctx, const uint8_t* src, int w, int h, int stride, uint8_t* dst, int dstride);
+/* The image levels of cv::buildOpticalFlowPyramid as calcOpticalFlowPyrLK builds them inside src/tracker.cpp:68 (pyrDown chain
+ * to cfg.lk_max_level, stopping early where a level would not exceed winSize), produced by the tracker's own pyramid path
+ * (levels 1..3 in one fused launch).  Level l (1-based) is written to levels[l - 1], rows tightly packed ((w_l) bytes per
+ * row, w_l = (w_{l-1} + 1) / 2); *n_levels = levels in use including level 0.  Parity tests. */
+int mvo_build_lk_pyramid(mvo_ctx* ctx, const uint8_t* img, int w, int h, int stride, uint8_t* const* levels, int* n_levels);
 
 /* ---- a5: Tracker::has_parallax / Initializer::check_parallax (src/tracker.cpp:237-268,
  * src/initializer.cpp:77-110) ----------------------------------------------------------------------

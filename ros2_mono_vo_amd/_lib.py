@@ -48,7 +48,7 @@ MATCH_DTYPE = np.dtype([("query_idx", "i4"), ("train_idx", "i4"), ("img_idx", "i
 ABI_SYMBOLS = [
     "mvo_config_default", "mvo_create", "mvo_destroy", "mvo_last_error", "mvo_version", "mvo_sync", "mvo_stream",
     "mvo_orb_detect_and_compute", "mvo_orb_detect", "mvo_fast9_nms", "mvo_retain_best", "mvo_match_knn2_ratio", "mvo_lk_track",
-    "mvo_pyrdown", "mvo_find_homography_ransac", "mvo_find_fundamental_ransac", "mvo_solve_pnp_ransac",
+    "mvo_pyrdown", "mvo_build_lk_pyramid", "mvo_find_homography_ransac", "mvo_find_fundamental_ransac", "mvo_solve_pnp_ransac",
     "mvo_find_essential_ransac", "mvo_recover_pose", "mvo_triangulate",
     "mvo_batch_preload_frame", "mvo_batch_seed", "mvo_batch_get_tracks", "mvo_batch_set_landmarks",
     "mvo_batch_set_intrinsics", "mvo_profile_enable", "mvo_profile_read", "mvo_profile_reset",

@@ -133,6 +133,19 @@ class Context:
         self._check(self._L.mvo_pyrdown(self._h, ptr(img), w, h, stride, ptr(out), out.shape[1]))
         return out
 
+    def build_lk_pyramid(self, img):
+        """Levels 1.. of the tracker's LK pyramid of `img` (mvo_build_lk_pyramid) -> list of uint8 arrays."""
+        img, w, h, stride, ch = self._img(img)
+        assert ch == 1
+        outs, ww, hh = [], w, h
+        for _ in range(3):
+            ww, hh = (ww + 1) // 2, (hh + 1) // 2
+            outs.append(np.zeros((hh, ww), np.uint8))
+        arr = (C.c_void_p * 3)(*[o.ctypes.data for o in outs])
+        n = C.c_int(0)
+        self._check(self._L.mvo_build_lk_pyramid(self._h, ptr(img), w, h, stride, arr, C.byref(n)))
+        return outs[:n.value - 1]
+
     # -- frame-batch mode ------------------------------------------------------------------------------
     def batch_preload_frame(self, slot, frame_idx, img):
         img, w, h, stride, ch = self._img(img)

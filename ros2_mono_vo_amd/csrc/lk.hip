@@ -16,6 +16,8 @@
 //                    convergence tests) is done by a row for its point, so one instruction serves four points.
 #include "mvo_internal.h"
 
+#include <cstdlib>
+
 // ---------------------------------------------------------------------------------------------------
 // pyrDown
 // ---------------------------------------------------------------------------------------------------
@@ -111,6 +113,155 @@ __global__ __launch_bounds__(256) void pyrdown_kernel(ImgSet src, ImgSet dst, Ti
 static void launch_pyrdown(mvo_ctx* ctx, const ImgSet& s, const ImgSet& d, int nslots, hipStream_t st) {
   TileGrid tg{(d.w + PD_TW - 1) / PD_TW, (d.h + PD_TH - 1) / PD_TH, nslots};
   hipLaunchKernelGGL(pyrdown_kernel, dim3(xcd_grid_blocks(tg)), dim3(256), 0, st, s, d, tg);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// pyramid levels 1..3 in ONE kernel
+// ---------------------------------------------------------------------------------------------------
+// A workgroup owns 16 x 16 pixels of level 3 = 32 x 32 of level 2 = 64 x 64 of level 1 = 128 x 128 of level 0 and reads its
+// level-0 neighbourhood ONCE: 149 rows x 160 bytes arrive by LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write),
+// every level is written to HBM once and nothing is read back.  With o_l the first coordinate of the level-l region
+// the tile needs (o3 = 16 T, o2 = 2 o3 - 2, o1 = 2 o2 - 2, level-0 origin 2 o1 - 4 = 128 T - 16: 16-byte aligned), region l
+// is 16 / 35 / 73 wide and the source tile of a level starts 4 bytes left of 2 o: pixel pair m of a row needs source bytes
+// 4m + 2 .. 4m + 8, i.e. dwords m, m + 1, m + 2 (the same v_dot4 form as pyrdown_kernel).
+// A thread owns a pair of output columns and walks down a strip of rows, keeping the five horizontal sums of the
+// sliding vertical window in registers (packed u16 pairs): there is no horizontal-pass tile.
+// cv::pyrDown's BORDER_REFLECT_101 applies per level to THAT level's image: out-of-image rows of level 0 are reflected at
+// load time, out-of-image rows of the level-1 / level-2 tiles by an index map when they are read, out-of-image columns
+// (at most two on either side) by a byte fix-up inside LDS; a reflected coordinate always lies inside the 5-tap window
+// that asks for it, hence inside the tile.
+#define P3_S0_ROWS 149
+#define P3_S0_PD 40     // dwords per level-0 tile row: ten 16-byte chunks, lane-linear (LDS-DMA writes 1 KiB per wave-instruction)
+#define P3_T1_ROWS 73
+#define P3_T1_PD 21     // level-1 tile: byte index = column - o1 + 2 (77 bytes used)
+#define P3_T2_ROWS 35
+#define P3_T2_PD 11     // level-2 tile: byte index = column - o2 + 2 (37 bytes used)
+struct Pyr3Args {
+  const u8* src; size_t src_stride; int w0, h0, p0;   // level 0 (e.g. a ring entry), slots src_stride apart
+  u8* l1; u8* l2; u8* l3; size_t dst_stride;          // levels 1..3 of the pyramid set
+  int w1, h1, p1, w2, h2, p2, w3, h3, p3;
+  TileGrid tg;                                        // tiles of 16 x 16 level-3 pixels x slots
+};
+
+__device__ __forceinline__ unsigned pd_hpair(unsigned d0, unsigned d1, unsigned d2) {
+  const unsigned o0 = __builtin_amdgcn_udot4(d0, 0x04010000u, __builtin_amdgcn_udot4(d1, 0x00010406u, 0u, false), false);
+  const unsigned o1 = __builtin_amdgcn_udot4(d1, 0x04060401u, d2 & 0xFFu, false);
+  return o0 | (o1 << 16);
+}
+// two output pixels (bytes 0 and 1 of the result) from five packed horizontal sums: (6 h2 + 4 (h1 + h3) + h0 + h4 + 128) >> 8
+__device__ __forceinline__ unsigned pd_vpair(unsigned a0, unsigned a1, unsigned a2, unsigned a3, unsigned a4) {
+  const pd_us2 h0 = __builtin_bit_cast(pd_us2, a0), h1 = __builtin_bit_cast(pd_us2, a1), h2 = __builtin_bit_cast(pd_us2, a2),
+               h3 = __builtin_bit_cast(pd_us2, a3), h4 = __builtin_bit_cast(pd_us2, a4);
+  const pd_us2 six = {6, 6}, four = {4, 4}, rnd = {128, 128};
+  const pd_us2 v = h2 * six + (h1 + h3) * four + h0 + h4 + rnd;
+  return (unsigned)(v.x >> 8) | ((unsigned)(v.y >> 8) << 8);
+}
+// Output rows j0 .. j0 + NR - 1 of pair-column p from a source tile with PD dwords per row; rmap(r) = tile row holding source
+// row r of the strip's window (r = 2 j .. 2 j + 4 for output row j); emit(j, two bytes).
+template <int NR, int PD, class RowMap, class Emit>
+__device__ __forceinline__ void pd_strip(const unsigned* __restrict__ src, int p, int j0, RowMap rmap, Emit emit) {
+  unsigned h[2 * NR + 3];
+#pragma unroll
+  for (int r = 0; r < 2 * NR + 3; r++) {
+    const unsigned* q = src + rmap(2 * j0 + r) * PD + p;
+    h[r] = pd_hpair(q[0], q[1], q[2]);
+    if (r >= 4 && !(r & 1)) emit(j0 + (r - 4) / 2, pd_vpair(h[r - 4], h[r - 3], h[r - 2], h[r - 1], h[r]));
+  }
+}
+// columns -2, -1 and w, w + 1 of a level tile <- their reflect-101 sources (byte index of column c is c - org); one thread per row
+__device__ __forceinline__ void pd_fix_cols(u8* row, int org, int w, int nbytes) {
+  if (org < 0) { row[-2 - org] = row[2 - org]; row[-1 - org] = row[1 - org]; }
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int c = w + j - org;
+    if (c >= 0 && c < nbytes) row[c] = row[w - 2 - j - org];
+  }
+}
+
+__global__ __launch_bounds__(256) void pyr3_kernel(Pyr3Args A) {
+  __shared__ __attribute__((aligned(16))) unsigned s0[P3_S0_ROWS * P3_S0_PD];
+  __shared__ unsigned t1[P3_T1_ROWS * P3_T1_PD];
+  __shared__ unsigned t2[P3_T2_ROWS * P3_T2_PD];
+  int bx, by, bz;
+  if (!xcd_tile(A.tg, bx, by, bz)) return;
+  const int tid = threadIdx.x;
+  const u8* sp = A.src + (size_t)bz * A.src_stride;
+  const int o1x = 64 * bx - 6, o1y = 64 * by - 6, o2x = 32 * bx - 2, o2y = 32 * by - 2;
+  const int x0 = 128 * bx - 16, y0 = 128 * by - 14;   // level-0 tile origin
+  // ---- level 0 -> LDS: chunk i (16 bytes) = tile row i / 10, bytes 16 (i % 10) ..; rows by reflect-101, chunks clamped
+  // into the row (what a clamped chunk holds is either never used or rewritten by the column fix-up)
+  {
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int it = 0; it < (P3_S0_ROWS * 10 + 255) / 256; it++) {
+      const int i0 = (it * 4 + wave) * 64, i = i0 + lane;
+      if (i < P3_S0_ROWS * 10) {
+        const int row = __umul24(i, 6554) >> 16, k = i - row * 10;   // i / 10 for i < 2^14
+        const int gy = d_reflect101(y0 + row, A.h0);
+        int gx = x0 + 16 * k;
+        gx = gx < 0 ? 0 : (gx + 16 > A.p0 ? A.p0 - 16 : gx);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sp + (size_t)__umul24(gy, A.p0) + gx),
+                                         (__attribute__((address_space(3))) void*)(s0 + i0 * 4), 16, 0, 0);
+      }
+    }
+  }
+  __syncthreads();   // the fence of the barrier waits for the DMA (vmcnt(0))
+  if (x0 < 0 || x0 + 4 * P3_S0_PD > A.w0) {   // block-uniform
+    if (tid < P3_S0_ROWS) pd_fix_cols((u8*)s0 + tid * (4 * P3_S0_PD), x0, A.w0, 4 * P3_S0_PD);
+    __syncthreads();
+  }
+  // ---- level 1: 37 pair-columns x 6 strips of 13 rows (73 x 73 region) -> t1 --------------------------------------------
+  if (tid < 37 * 6) {
+    const int seg = __umul24(tid, 1772) >> 16, p = tid - seg * 37;   // tid / 37 for tid < 2^11
+    unsigned short* out = (unsigned short*)t1 + 1 + p;               // byte index 2 + 2 p of a row
+    pd_strip<13, P3_S0_PD>(s0, p, 13 * seg, [](int r) { return r < P3_S0_ROWS ? r : P3_S0_ROWS - 1; },
+                           [&](int j, unsigned v) { if (j < P3_T1_ROWS) out[j * (2 * P3_T1_PD)] = (unsigned short)v; });
+  }
+  __syncthreads();
+  if (o1x < 0 || o1x - 2 + 4 * P3_T1_PD > A.w1) {
+    if (tid < P3_T1_ROWS) pd_fix_cols((u8*)t1 + tid * (4 * P3_T1_PD), o1x - 2, A.w1, 4 * P3_T1_PD);
+    __syncthreads();
+  }
+  // ---- level 1 -> HBM (own 64 x 64: 16 bytes per thread); level 2: 18 pair-columns x 14 strips of 3 rows -> t2 -----------------
+  {
+    const int row = tid >> 2, q = tid & 3;
+    const int y = 64 * by + row, x = 64 * bx + 16 * q;
+    if (y < A.h1 && x < A.p1) {
+      const unsigned* r = t1 + (6 + row) * P3_T1_PD + 2 + 4 * q;   // byte index 8 = column 64 bx
+      *(uint4*)(A.l1 + (size_t)bz * A.dst_stride + (size_t)__umul24(y, A.p1) + x) = make_uint4(r[0], r[1], r[2], r[3]);
+    }
+  }
+  if (tid < 18 * 14) {
+    const int seg = __umul24(tid, 3641) >> 16, p = tid - seg * 18;   // tid / 18
+    unsigned short* out = (unsigned short*)t2 + 1 + p;
+    const int h1 = A.h1;
+    pd_strip<3, P3_T1_PD>(t1, p, 3 * seg,
+                          [&](int r) { int j = d_reflect101(o1y + r, h1) - o1y; return j < 0 ? 0 : (j < P3_T1_ROWS ? j : P3_T1_ROWS - 1); },
+                          [&](int j, unsigned v) { if (j < P3_T2_ROWS) out[j * (2 * P3_T2_PD)] = (unsigned short)v; });
+  }
+  __syncthreads();
+  if (o2x < 0 || o2x - 2 + 4 * P3_T2_PD > A.w2) {
+    if (tid < P3_T2_ROWS) pd_fix_cols((u8*)t2 + tid * (4 * P3_T2_PD), o2x - 2, A.w2, 4 * P3_T2_PD);
+    __syncthreads();
+  }
+  // ---- level 2 -> HBM (own 32 x 32); level 3: 8 pair-columns x 16 rows straight to HBM ---------------------------------------
+  if (tid < 64) {
+    const int row = tid >> 1, q = tid & 1;
+    const int y = 32 * by + row, x = 32 * bx + 16 * q;
+    if (y < A.h2 && x < A.p2) {
+      const unsigned* r = t2 + (2 + row) * P3_T2_PD + 1 + 4 * q;   // byte index 4 = column 32 bx
+      *(uint4*)(A.l2 + (size_t)bz * A.dst_stride + (size_t)__umul24(y, A.p2) + x) = make_uint4(r[0], r[1], r[2], r[3]);
+    }
+  } else if (tid < 64 + 128) {
+    const int t = tid - 64, row = t >> 3, p = t & 7;
+    const int y = 16 * by + row, x = 16 * bx + 2 * p;
+    const int h2 = A.h2;
+    u8* dst = A.l3 + (size_t)bz * A.dst_stride;
+    const int w3 = A.w3, h3 = A.h3, p3 = A.p3;
+    pd_strip<1, P3_T2_PD>(t2, p, row,
+                          [&](int r) { int j = d_reflect101(o2y + r, h2) - o2y; return j < 0 ? 0 : (j < P3_T2_ROWS ? j : P3_T2_ROWS - 1); },
+                          [&](int, unsigned v) { if (y < h3 && x < w3) *(unsigned short*)(dst + (size_t)__umul24(y, p3) + x) = (unsigned short)v; });
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -649,6 +800,20 @@ static ImgSet lk_imgset(mvo_ctx* ctx, int set, const LkLevels& L, int level) {
 // the frame ring) or, when null, the set's own level 0 (slot 0 only: the per-call API).
 int lk_build_pyramid(mvo_ctx* ctx, int set, const LkLevels& L, int nslots, hipStream_t st, const u8* l0, size_t l0_stride) {
   if (!st) st = ctx->stream;
+  static const bool fused = !(getenv("MVO_PYR_FUSED") && atoi(getenv("MVO_PYR_FUSED")) == 0);
+  if (fused && L.n == 4 && L.w[3] >= 8 && L.h[3] >= 8) {   // all of levels 1..3 in one launch, level 0 read once
+    ImgSet s0 = lk_imgset(ctx, set, L, 0);
+    if (l0) { s0.base = const_cast<u8*>(l0); s0.slot_stride = l0_stride; }
+    Pyr3Args A;
+    A.src = s0.base; A.src_stride = s0.slot_stride; A.w0 = L.w[0]; A.h0 = L.h[0]; A.p0 = L.pitch[0];
+    A.l1 = lk_imgset(ctx, set, L, 1).base; A.l2 = lk_imgset(ctx, set, L, 2).base; A.l3 = lk_imgset(ctx, set, L, 3).base;
+    A.dst_stride = ctx->lk_slot_bytes;
+    A.w1 = L.w[1]; A.h1 = L.h[1]; A.p1 = L.pitch[1]; A.w2 = L.w[2]; A.h2 = L.h[2]; A.p2 = L.pitch[2];
+    A.w3 = L.w[3]; A.h3 = L.h[3]; A.p3 = L.pitch[3];
+    A.tg = TileGrid{(L.w[3] + 15) / 16, (L.h[3] + 15) / 16, nslots};
+    hipLaunchKernelGGL(pyr3_kernel, dim3(xcd_grid_blocks(A.tg)), dim3(256), 0, st, A);
+    return MVO_OK;
+  }
   for (int l = 1; l < L.n; l++) {
     ImgSet src = lk_imgset(ctx, set, L, l - 1);
     if (l == 1 && l0) { src.base = const_cast<u8*>(l0); src.slot_stride = l0_stride; }
@@ -704,6 +869,25 @@ extern "C" int mvo_pyrdown(mvo_ctx* ctx, const uint8_t* src, int w, int h, int s
   launch_pyrdown(ctx, s, d, 1, ctx->stream);
   MVO_HIP(hipMemcpy2DAsync(dst, dstride, d.base, d.pitch, d.w, d.h, hipMemcpyDeviceToHost, ctx->stream));
   MVO_HIP(hipStreamSynchronize(ctx->stream));
+  return MVO_OK;
+}
+
+// Levels 1.. of the LK pyramid of one image exactly as the tracker builds them (cv::buildOpticalFlowPyramid's images: pyrDown
+// chain, early stop when a level would not exceed winSize): level l goes to levels[l - 1], rows tightly packed.
+extern "C" int mvo_build_lk_pyramid(mvo_ctx* ctx, const uint8_t* img, int w, int h, int stride, uint8_t* const* levels, int* n_levels) {
+  if (!ctx || !img || !levels || !n_levels || w < 1 || h < 1 || w > ctx->maxw || h > ctx->maxh) return MVO_E_ARG;
+  LkLevels L = lk_levels(w, h, ctx->cfg.lk_win, ctx->cfg.lk_max_level);
+  ImgSet s = lk_imgset(ctx, 0, L, 0);
+  int rc = upload_gray(ctx, img, w, h, stride, 1, s.base, s.pitch, 0);
+  if (rc) return rc;
+  lk_build_pyramid(ctx, 0, L, 1);
+  for (int l = 1; l < L.n; l++) {
+    if (!levels[l - 1]) return MVO_E_ARG;
+    ImgSet d = lk_imgset(ctx, 0, L, l);
+    MVO_HIP(hipMemcpy2DAsync(levels[l - 1], d.w, d.base, d.pitch, d.w, d.h, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  MVO_HIP(hipStreamSynchronize(ctx->stream));
+  *n_levels = L.n;
   return MVO_OK;
 }
 

@@ -169,3 +169,13 @@ def make_plane_scene(seed: int = 7, scale: float = 1.0):
         t = base_texture(640, 480, seed + 10 + i, margin=0)
         planes.append(dict(z=z, x0=cx - sw, x1=cx + sw, y0=cy - sh, y1=cy + sh, tex=t, ppm=t.shape[1] / (2 * sw)))
     return planes
+
+
+def depth_landmarks(K: np.ndarray, depth0: np.ndarray, xy: np.ndarray) -> np.ndarray:
+    """Landmarks of frame-0 key-points from a renderer's depth map (camera 0 = world): X = z K^-1 (x, y, 1), float32."""
+    xi = np.clip(np.rint(xy[:, 0]).astype(int), 0, depth0.shape[1] - 1)
+    yi = np.clip(np.rint(xy[:, 1]).astype(int), 0, depth0.shape[0] - 1)
+    z = depth0[yi, xi]
+    z = np.where(np.isfinite(z), z, 10.0).astype(np.float32)
+    return np.stack([(xy[:, 0] - np.float32(K[0, 2])) / np.float32(K[0, 0]) * z,
+                     (xy[:, 1] - np.float32(K[1, 2])) / np.float32(K[1, 1]) * z, z], 1).astype(np.float32)

@@ -100,11 +100,4 @@ def render_stream(bank: SceneBank, params, K: np.ndarray, w: int, h: int, n_fram
     return img.round().clamp(0, 255).to(torch.uint8), depth[0]
 
 
-def depth_landmarks(K: np.ndarray, depth0: np.ndarray, xy: np.ndarray) -> np.ndarray:
-    """Landmarks of frame-0 key-points from the renderer's depth (camera 0 = world): X = z K^-1 (x, y, 1), float32."""
-    xi = np.clip(np.rint(xy[:, 0]).astype(int), 0, depth0.shape[1] - 1)
-    yi = np.clip(np.rint(xy[:, 1]).astype(int), 0, depth0.shape[0] - 1)
-    z = depth0[yi, xi]
-    z = np.where(np.isfinite(z), z, 10.0).astype(np.float32)
-    return np.stack([(xy[:, 0] - np.float32(K[0, 2])) / np.float32(K[0, 0]) * z,
-                     (xy[:, 1] - np.float32(K[1, 2])) / np.float32(K[1, 1]) * z, z], 1).astype(np.float32)
+from .synth import depth_landmarks  # noqa: E402,F401  (numpy only: the CPU-oracle workers use it without importing torch)

@@ -34,7 +34,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        path = os.path.join(_ODIR, "liborc.so")
+        path = os.environ.get("MVO_ORACLE_LIB") or os.path.join(_ODIR, "liborc.so")   # MVO_ORACLE_LIB: another build of the same sources (bench.py's timing leg)
         if not os.path.exists(path):
             build()
         _lib = C.CDLL(path)

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import oracle_py as O
-from ros2_mono_vo_amd import synth
+from ros2_mono_vo_amd import Context, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -35,6 +35,32 @@ def test_pyrdown_bitexact(ctx720, frames720):
     for h, w in ((33, 64), (64, 130), (17, 259), (200, 61), (9, 8), (5, 7), (3, 9), (2, 2), (2, 3), (3, 2), (1, 5), (4, 1), (1, 1)):
         small = np.ascontiguousarray(frames720[1][100:100 + h, 300:300 + w])
         assert np.array_equal(ctx720.pyrdown(small), O.pyrdown(small)), (h, w)
+
+
+@pytest.mark.parametrize("w,h", [(1280, 720), (640, 480), (1241, 376), (1920, 1080), (1279, 719), (177, 177), (333, 180), (200, 1000),
+                                 (1025, 769), (176, 176), (175, 300)])
+def test_lk_pyramid_fused_levels_bitexact(w, h):
+    """The tracker's pyramid path (levels 1..3 in ONE launch, csrc/lk.hip pyr3_kernel; per-level kernels where fewer than
+    four levels exist) against a chain of the oracle's cv::pyrDown: every level identical, at sizes that put image borders,
+    odd widths / heights and partial tiles on every side of the 128 x 128 tiles, down to the smallest 4-level image."""
+    rng = np.random.default_rng(w * 10007 + h)
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    img[: h // 3] = 255          # saturated and dark bands: the rounding of (sum + 128) >> 8 at both ends of the range
+    img[h // 3: h // 2, : w // 2] = 0
+    with Context(max_width=w, max_height=h, nfeatures=500) as ctx:
+        got = ctx.build_lk_pyramid(img)
+    want, cur = [], img
+    for _ in range(3):
+        nw, nh = (cur.shape[1] + 1) // 2, (cur.shape[0] + 1) // 2
+        if nw <= 21 or nh <= 21:
+            break
+        cur = O.pyrdown(cur)
+        want.append(cur)
+    assert len(got) == len(want)
+    for l, (g, o) in enumerate(zip(got, want)):
+        bad = np.argwhere(g != o)
+        assert g.shape == o.shape and len(bad) == 0, (l + 1, g.shape, o.shape, bad[:5].tolist())
+
 
 
 def test_fast_corner_indices_bitexact(ctx720, frames720, frames480):
