@@ -74,6 +74,7 @@ def parse_args():
     ap.add_argument("--max-points", type=int, default=None, help="track capacity per stream (default 4096; 8192 above 2000 features)")
     ap.add_argument("--ingest-steps", type=int, default=16, help="steps of the value_with_ingest phase (0 = skip)")
     ap.add_argument("--ingest-ring", type=int, default=3, help="ring entries the ingest phase cycles through (uploads run ring - 1 frames ahead)")
+    ap.add_argument("--depth", type=int, default=1, help="steps kept in flight per context (1 or 2: mvo_batch_track_async pipelines two)")
     ap.add_argument("--extra-steps", type=int, default=5, help="steps of the always-on and key-frame-every-frame phases (0 = skip)")
     ap.add_argument("--single-steps", type=int, default=30, help="steps of the single-stream measurement (0 = skip)")
     ap.add_argument("--cpu-streams", type=int, default=None, help="streams checked against the CPU oracle (default: host cores)")
@@ -441,9 +442,10 @@ def main():
                 ctxs[c].batch_upload_async((k + RING - 1) % RING, pins[c][k + RING - 1].ctypes.data, W, H, pitch, H * pitch)
             sent[c] += 1
 
-        for c in range(C):
-            if n_steps:
-                enqueue(c)
+        for _ in range(max(1, min(2, args.depth))):     # steps in flight per context: the next one is queued behind the running one,
+            for c in range(C):                           # so a context's stream never waits for this loop between two steps
+                if sent[c] < n_steps:
+                    enqueue(c)
         while min(done) < n_steps:
             progressed = False
             for c, ctx in enumerate(ctxs):      # a context whose step has finished is collected and re-armed at once;

@@ -230,10 +230,12 @@ int mvo_batch_set_intrinsics(mvo_ctx* ctx, const double K[9], const double d[5])
  * pass - run over a compacted device-resident slot list.  No host wait inside a step: launches are sized for the worst
  * case and read the real counts on the device, so a step can be enqueued asynchronously and several contexts interleave
  * on one GPU.  Seed with mvo_batch_seed + mvo_batch_set_landmarks (the Initializer's hand-over, src/mono_vo.cpp:102-105).
- *   mvo_batch_track_async  enqueue the step on ring frame `frame_idx`; returns at once
- *   mvo_batch_track_poll   1 when the enqueued step has finished, 0 while it runs
- *   mvo_batch_track_wait   block until it has finished, copy the per-slot results to out[batch] (may be NULL);
- *                          MVO_E_CAPACITY if a device-side capacity was exceeded (results clamped)
+ *   mvo_batch_track_async  enqueue the step on ring frame `frame_idx`; returns at once.  TWO steps may be in flight: enqueue
+ *                          frame k+1 while frame k still runs and the device never waits for the host between them
+ *                          (a third call before a wait is MVO_E_ARG)
+ *   mvo_batch_track_poll   1 when the OLDEST step in flight has finished (or none is in flight), 0 while it runs
+ *   mvo_batch_track_wait   block until the oldest step in flight has finished, copy its per-slot results to out[batch] (may be
+ *                          NULL); MVO_E_CAPACITY if a device-side capacity was exceeded (results clamped)
  *   mvo_batch_track        both
  *   mvo_batch_set_policy   0: the reference's key-frame policy (default); benchmarking loads (LOST handling
  *                          unchanged): 1 = key-frame branch on every tracked frame (worst case), 2 = never a key-frame

@@ -39,6 +39,12 @@ struct RansacArgs {
   int* result;    // [B][8]: ok, n_inliers, iters_run, niters_final, models_scored, [5] (idx != null) entries of the index list
   int* idx;       // [B][idx_stride] ordered list of the consensus set (solvePnPRansac's `inliers`), or null
   int idx_stride;
+  // Slot queue (null: workgroup b solves slot b).  The launch is `grid` persistent workgroups that claim slots 0 .. nslots - 1
+  // from *work_ctr (zeroed before the launch) and skip the ones without correspondences.  A workgroup is placed only where its
+  // LDS fits (H: 138 KB - an empty CU), so on a step where few or no slots need the model a launch of one workgroup per slot
+  // spent a millisecond or more just getting its empty workgroups placed and retired (trace: profiles/r03_c_step_timeline.txt).
+  int* work_ctr;
+  int nslots;
 };
 
 // Candidate samples per round = M::CH (16 for H / F / PnP): their solvers keep the dense matrices in a per-lane LDS
@@ -91,7 +97,7 @@ __device__ inline void ransac_mask_to_indices(const u8* mask, int count, int* id
 }
 
 template <class M, int NW>
-__global__ __launch_bounds__(64 * NW, RS_WAVES_PER_EU) void ransac_kernel(RansacArgs A) {
+__device__ __forceinline__ void ransac_slot(const RansacArgs& A, const int slot) {
   constexpr int RS_TT = 64 * NW;
   static_assert(NW == 1 || !M::WIDE, "wide (private-memory) rounds are a single-wave mode");
   // Round width.  The first round (and any round with few iterations left) solves CH0 = M::CH hypotheses, whose dense
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(64 * NW, RS_WAVES_PER_EU) void ransac_kernel(Ransac
   __shared__ int s_idx[RS_Q][M::MP];
   __shared__ int s_qn;   // passing candidates queued
   __shared__ int s_lwave[NW], s_lbase;   // ordered inlier list (A.idx)
-  int* const out_idx = A.idx ? A.idx + (size_t)blockIdx.x * A.idx_stride : nullptr;
+  int* const out_idx = A.idx ? A.idx + (size_t)slot * A.idx_stride : nullptr;
   __shared__ double s_models[RS_CH][M::MAXM][M::MS];
   __shared__ int s_nmodels[RS_CH];
   __shared__ int s_cnt[RS_CH][M::MAXM];
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(64 * NW, RS_WAVES_PER_EU) void ransac_kernel(Ransac
   // one latency-bound wavefront per stream next to VALU-saturating image kernels: without priority it only gets a
   // round-robin share of the SIMD's issue slots and a hard stream's chain (5 x the instructions) gates the step
   __builtin_amdgcn_s_setprio(3);
-  const int slot = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int count = min(max(A.n[slot], 0), A.cap);
   const float* m1 = A.m1 + (size_t)slot * A.stride1;
   const float* m2 = A.m2 + (size_t)slot * A.stride2;
@@ -418,6 +424,20 @@ __global__ __launch_bounds__(64 * NW, RS_WAVES_PER_EU) void ransac_kernel(Ransac
     printf("RS_TIMING MP=%d slot=%d n=%d iters=%d scored=%d | draw %lld check %lld solve %lld score %lld replay %lld mask %lld (100MHz ticks)\n", M::MP, slot, count,
            s_ctl[3], s_ctl[7], tm[0], tm[1], tm[2], tm[3], tm[4], tm[5]);
 #endif
+}
+
+template <class M, int NW>
+__global__ __launch_bounds__(64 * NW, RS_WAVES_PER_EU) void ransac_kernel(RansacArgs A) {
+  if (!A.work_ctr) { ransac_slot<M, NW>(A, blockIdx.x); return; }
+  __shared__ int s_claim;
+  for (;;) {   // every workgroup leaves once the counter has passed the last slot
+    __syncthreads();   // the shared state of the slot just solved is dead
+    if (threadIdx.x == 0) s_claim = atomicAdd(A.work_ctr, 1);
+    __syncthreads();
+    const int slot = s_claim;
+    if (slot >= A.nslots) return;
+    ransac_slot<M, NW>(A, slot);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -960,28 +980,30 @@ void geom_state_destroy(mvo_ctx* ctx) {
 template <class M, int NW = 1>
 static void launch_ransac(mvo_ctx* ctx, hipStream_t st, int nslots, const float* m1, const float* m2, int stride1, int stride2,
                           const int* d_n, double thr, double conf, int max_iters, const ModelParams& P, u8* mask, int mask_stride,
-                          double* model, int* result, int* idx = nullptr, int idx_stride = 0) {
+                          double* model, int* result, int* idx = nullptr, int idx_stride = 0, int* work_ctr = nullptr, int grid = 0) {
   RansacArgs A;
-  A.idx = idx; A.idx_stride = idx_stride;
+  A.idx = idx; A.idx_stride = idx_stride; A.work_ctr = work_ctr; A.nslots = nslots;
   A.m1 = m1; A.m2 = m2; A.stride1 = stride1; A.stride2 = stride2; A.n = d_n;
   A.thr = thr; A.conf = conf; A.max_iters = max_iters; A.cap = ctx->maxpts; A.P = P;
   A.mask = mask; A.mask_stride = mask_stride; A.model = model; A.result = result;
-  hipLaunchKernelGGL((ransac_kernel<M, NW>), dim3(nslots), dim3(64 * NW), 0, st, A);
+  hipLaunchKernelGGL((ransac_kernel<M, NW>), dim3(work_ctr ? (grid < 1 ? 1 : (grid > nslots ? nslots : grid)) : nslots), dim3(64 * NW), 0, st, A);
 }
 
 // Device-level drivers used by the pipeline (inputs already resident, all slots per launch).
 int geom_ransac_h(mvo_ctx* ctx, int nslots, const float* p1, const float* p2, const int* d_n, double thr, int max_iters, double conf,
-                  u8* mask, double* model, int* result, hipStream_t st) {
+                  u8* mask, double* model, int* result, hipStream_t st, int* work_ctr, int grid) {
   if (!st) st = ctx->stream;
   ModelParams P{};
-  launch_ransac<HModel, RS_H_NW>(ctx, st, nslots, p1, p2, ctx->maxpts * 2, ctx->maxpts * 2, d_n, thr, conf, max_iters, P, mask, ctx->maxpts, model, result);
+  launch_ransac<HModel, RS_H_NW>(ctx, st, nslots, p1, p2, ctx->maxpts * 2, ctx->maxpts * 2, d_n, thr, conf, max_iters, P, mask, ctx->maxpts, model, result,
+                                 nullptr, 0, work_ctr, grid);
   return MVO_OK;
 }
 int geom_ransac_f(mvo_ctx* ctx, int nslots, const float* p1, const float* p2, const int* d_n, double thr, int max_iters, double conf,
-                  u8* mask, double* model, int* result, hipStream_t st) {
+                  u8* mask, double* model, int* result, hipStream_t st, int* work_ctr, int grid) {
   if (!st) st = ctx->stream;
   ModelParams P{};
-  launch_ransac<FModel>(ctx, st, nslots, p1, p2, ctx->maxpts * 2, ctx->maxpts * 2, d_n, thr, conf, max_iters, P, mask, ctx->maxpts, model, result);
+  launch_ransac<FModel>(ctx, st, nslots, p1, p2, ctx->maxpts * 2, ctx->maxpts * 2, d_n, thr, conf, max_iters, P, mask, ctx->maxpts, model, result,
+                        nullptr, 0, work_ctr, grid);
   return MVO_OK;
 }
 int geom_pnp(mvo_ctx* ctx, int nslots, const float* obj, const float* img, const int* d_n, const double K[9], const double* dist5, int iters,

@@ -264,10 +264,11 @@ int orb_select_device(mvo_ctx* ctx, const OrbGeom& G, int nslots, const int* d_n
 int orb_run_device(mvo_ctx* ctx, int w, int h, int max_slots, const int* d_nact);  // device-driven detect + describe (no host wait)
 // d_list / d_nlist (optional): run only the *d_nlist slots named by the device-resident list (grid sized for nslots)
 int match_device(mvo_ctx* ctx, int nslots, int max_nq, double ratio, const int* d_list = nullptr, const int* d_nlist = nullptr);
+// work_ctr / grid: see RansacArgs::work_ctr (persistent workgroups over a slot queue); null = one workgroup per slot
 int geom_ransac_h(mvo_ctx* ctx, int nslots, const float* p1, const float* p2, const int* d_n, double thr, int max_iters, double conf,
-                  u8* mask, double* model, int* result, hipStream_t st);
+                  u8* mask, double* model, int* result, hipStream_t st, int* work_ctr = nullptr, int grid = 0);
 int geom_ransac_f(mvo_ctx* ctx, int nslots, const float* p1, const float* p2, const int* d_n, double thr, int max_iters, double conf,
-                  u8* mask, double* model, int* result, hipStream_t st);
+                  u8* mask, double* model, int* result, hipStream_t st, int* work_ctr = nullptr, int grid = 0);
 int geom_pnp(mvo_ctx* ctx, int nslots, const float* obj, const float* img, const int* d_n, const double K[9], const double* dist5, int iters,
              float reproj, double conf, u8* mask, double* model, int* result, int* inl, double* pose, hipStream_t st);
 int geom_triangulate_matches(mvo_ctx* ctx, int nslots, int max_matches, const mvo_match* matches, const int* n_matches,

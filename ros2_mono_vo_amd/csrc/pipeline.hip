@@ -6,6 +6,8 @@
 
 #include <dlfcn.h>
 
+#include <cstdlib>
+
 #include <map>
 
 // ---------------------------------------------------------------------------------------------------
@@ -179,21 +181,22 @@ __global__ __launch_bounds__(256) void ring_to_orb0_kernel(const u8* __restrict_
 }
 
 // Tracker::track_frame_with_optical_flow's keep rule (src/tracker.cpp:70-77): status && err < thresh,
-// order preserved.  One block per slot.
-__global__ __launch_bounds__(1024) void lk_filter_compact_kernel(const float* __restrict__ next_pts, const u8* __restrict__ status,
+// order preserved.  One block of four wavefronts per slot (a 16-wave block has to find a whole CU free at once).
+#define LKF_T 256
+__global__ __launch_bounds__(LKF_T) void lk_filter_compact_kernel(const float* __restrict__ next_pts, const u8* __restrict__ status,
                                                                  const float* __restrict__ err, const int* __restrict__ npts,
                                                                  const float* __restrict__ lm, const float* __restrict__ kf,
                                                                  float thresh, int maxpts, float* __restrict__ o_pts,
                                                                  float* __restrict__ o_lm, float* __restrict__ o_kf,
                                                                  int* __restrict__ o_n) {
-  __shared__ int s_wave[16];
+  __shared__ int s_wave[LKF_T / 64];
   __shared__ int s_base;
   const int slot = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = npts[slot];
   const size_t b = (size_t)slot * maxpts;
   if (threadIdx.x == 0) s_base = 0;
   __syncthreads();
-  for (int i0 = 0; i0 < n; i0 += 1024) {
+  for (int i0 = 0; i0 < n; i0 += LKF_T) {
     int i = i0 + threadIdx.x;
     bool keep = i < n && status[b + i] && err[b + i] < thresh;
     unsigned long long m = __ballot(keep);
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(1024) void lk_filter_compact_kernel(const float* __
     __syncthreads();
     if (threadIdx.x == 0) {
       int t = 0;
-      for (int w = 0; w < 16; w++) t += s_wave[w];
+      for (int w = 0; w < LKF_T / 64; w++) t += s_wave[w];
       s_base += t;
     }
     __syncthreads();
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(1024) void lk_filter_compact_kernel(const float* __
 
 void lk_filter_compact_launch(mvo_ctx* ctx, hipStream_t st) {
   PipeState* p = ctx->pipe;
-  hipLaunchKernelGGL(lk_filter_compact_kernel, dim3(ctx->B), dim3(1024), 0, st, ctx->d_next_pts, ctx->d_status, ctx->d_err, ctx->d_npts,
+  hipLaunchKernelGGL(lk_filter_compact_kernel, dim3(ctx->B), dim3(LKF_T), 0, st, ctx->d_next_pts, ctx->d_status, ctx->d_err, ctx->d_npts,
                      p->d_lm, p->d_kf_pts, ctx->cfg.tracking_error_thresh, ctx->maxpts, p->d_cur_pts, p->d_cur_lm, p->d_cur_kf, p->d_ncur);
 }
 

@@ -35,17 +35,23 @@ struct TrackState {
   int* d_pt_base = nullptr;    // [B+1] LK work list: first item of each slot
   int* d_work_slot = nullptr;  // [B*maxpts] LK work list: slot of each item
   int* d_work_ctr = nullptr;   // [8] claim counters of the LK work list, one per XCD part
+  int* d_hf_ctr = nullptr;     // [2] slot-queue counters of the H and the F launch (zeroed by trk_policy_keyframe_kernel)
+  bool res_valid = false;      // h_res holds the results of the step collected last (host-side forecast of the key-frame tests)
   int* d_err = nullptr;        // [1] capacity flags raised on the device
   u8* d_mask_f = nullptr;      // [B][maxpts] F consensus mask (H uses geom->d_mask2)
   double* d_model_f = nullptr; // [B][16]
   int* d_result_f = nullptr;   // [B][8]
   mvo_step_result* d_res = nullptr;  // [B]
-  mvo_step_result* h_res = nullptr;  // pinned
-  int* h_err = nullptr;              // pinned [1]
+  // Up to TRK_DEPTH steps may be in flight (enqueued, not yet collected): the next step is enqueued while the previous one still
+  // runs, so the stream never waits for the host between two steps (measured: 3.7 ms median from a step's last kernel to the
+  // next step's first one when every step was collected before the next was enqueued).  Results land in a ring of pinned buffers.
+  mvo_step_result* h_res[2] = {nullptr, nullptr};  // pinned, [TRK_DEPTH][B]
+  int* h_err[2] = {nullptr, nullptr};              // pinned [1] each
+  mvo_step_result* last_res = nullptr;             // [B] results of the step collected last (host-side forecast)
   int policy = 0;              // 0: the reference's key-frame policy, 1: key-frame branch on every tracked frame (worst case),
                                // 2: never a key-frame (the always-on part of the step: LK + PnP)
-  bool pending = false;
-  hipEvent_t ev_done = nullptr;
+  int npending = 0, head = 0;    // steps in flight; ring index of the oldest
+  hipEvent_t ev_done[2] = {nullptr, nullptr};
   hipEvent_t ev_lk = nullptr;   // this context's latest LK launch has finished
   // output side (mvo_batch_enable_output): what MonoVO::image_callback derives from the tracker's result on every frame
   bool out_on = false;
@@ -69,6 +75,7 @@ static bool lk_turns() {
   return on;
 }
 
+#define TRK_DEPTH 2
 #define TRK_ERR_KEYPOINTS 1   // a slot's key-points exceeded max_points (clamped)
 #define TRK_ERR_CAND 2        // FAST candidates exceeded the candidate capacity (clamped)
 #define TRK_ERR_KPCAP 4       // dense key-point capacity exceeded (clamped)
@@ -166,8 +173,10 @@ __global__ __launch_bounds__(256) void trk_policy_keyframe_kernel(int* __restric
                                                                   const double* __restrict__ pose, const double* __restrict__ kf_pose,
                                                                   long long min_obs, long long max_after, double max_trans,
                                                                   double max_rot, int policy, int* __restrict__ n_hf,
-                                                                  int* __restrict__ flags, mvo_step_result* __restrict__ res) {
+                                                                  int* __restrict__ flags, mvo_step_result* __restrict__ res,
+                                                                  int* __restrict__ hf_ctr) {
   const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s < 2) hf_ctr[s] = 0;   // slot queues of the H and F launches that follow
   if (s >= B) return;
   int nhf = 0;
   const int n = n_pnp[s];
@@ -581,13 +590,18 @@ static int trk_create(mvo_ctx* ctx) {
   MVO_HIP(hipMalloc(&t->d_work_slot, np * sizeof(int)));
   MVO_HIP(hipMalloc(&t->d_work_ctr, 8 * sizeof(int)));
   MVO_HIP(hipMalloc(&t->d_err, sizeof(int)));
+  MVO_HIP(hipMalloc(&t->d_hf_ctr, 2 * sizeof(int)));
   MVO_HIP(hipMalloc(&t->d_mask_f, np));
   MVO_HIP(hipMalloc(&t->d_model_f, (size_t)B * 16 * sizeof(double)));
   MVO_HIP(hipMalloc(&t->d_result_f, (size_t)B * 8 * sizeof(int)));
   MVO_HIP(hipMalloc(&t->d_res, (size_t)B * sizeof(mvo_step_result)));
-  MVO_HIP(hipHostMalloc(&t->h_res, (size_t)B * sizeof(mvo_step_result), hipHostMallocDefault));
-  MVO_HIP(hipHostMalloc(&t->h_err, sizeof(int), hipHostMallocDefault));
-  MVO_HIP(hipEventCreateWithFlags(&t->ev_done, hipEventDisableTiming));
+  for (int i = 0; i < TRK_DEPTH; i++) {
+    MVO_HIP(hipHostMalloc(&t->h_res[i], (size_t)B * sizeof(mvo_step_result), hipHostMallocDefault));
+    MVO_HIP(hipHostMalloc(&t->h_err[i], sizeof(int), hipHostMallocDefault));
+    *t->h_err[i] = 0;
+    MVO_HIP(hipEventCreateWithFlags(&t->ev_done[i], hipEventDisableTiming));
+  }
+  t->last_res = (mvo_step_result*)calloc((size_t)B, sizeof(mvo_step_result));
   MVO_HIP(hipEventCreateWithFlags(&t->ev_lk, hipEventDisableTiming));
   MVO_HIP(hipMemsetAsync(t->d_state, 0, B * sizeof(int), ctx->stream));
   MVO_HIP(hipMemsetAsync(t->d_count, 0, B * sizeof(int), ctx->stream));
@@ -608,13 +622,16 @@ void trk_destroy(mvo_ctx* ctx) {
   TrackState* t = p->trk;
   if (!t) return;
   void* dev[] = {t->d_state, t->d_count, t->d_flags, t->d_n_pnp, t->d_n_hf, t->d_kf_list, t->d_nkf, t->d_pt_base, t->d_work_slot,
-                 t->d_work_ctr, t->d_err, t->d_mask_f, t->d_model_f, t->d_result_f, t->d_res};
+                 t->d_work_ctr, t->d_err, t->d_hf_ctr, t->d_mask_f, t->d_model_f, t->d_result_f, t->d_res};
   for (void* q : dev) (void)hipFree(q);
   void* outb[] = {t->d_cloud, t->d_n_cloud, t->d_path, t->d_n_path, t->d_ros};
   for (void* q : outb) if (q) (void)hipFree(q);
-  if (t->h_res) (void)hipHostFree(t->h_res);
-  if (t->h_err) (void)hipHostFree(t->h_err);
-  if (t->ev_done) (void)hipEventDestroy(t->ev_done);
+  for (int i = 0; i < TRK_DEPTH; i++) {
+    if (t->h_res[i]) (void)hipHostFree(t->h_res[i]);
+    if (t->h_err[i]) (void)hipHostFree(t->h_err[i]);
+    if (t->ev_done[i]) (void)hipEventDestroy(t->ev_done[i]);
+  }
+  free(t->last_res);
   if (t->ev_lk) {
     std::lock_guard<std::mutex> lock(g_lk_mu);
     if (lk_last(ctx) == t->ev_lk) lk_last(ctx) = nullptr;
@@ -761,12 +778,30 @@ static int trk_step_enqueue(mvo_ctx* ctx, int frame_idx) {
   }
   hipLaunchKernelGGL(trk_policy_keyframe_kernel, dim3(nb), dim3(256), 0, st, t->d_state, t->d_count, B, t->d_n_pnp, g->d_result, g->d_pose,
                      p->d_kf_pose, (long long)c.min_observations_before_triangulation, (long long)c.max_tracking_after_keyframe,
-                     c.max_translation_from_keyframe, c.max_rotation_from_keyframe, t->policy, t->d_n_hf, t->d_flags, t->d_res);
+                     c.max_translation_from_keyframe, c.max_rotation_from_keyframe, t->policy, t->d_n_hf, t->d_flags, t->d_res, t->d_hf_ctr);
   // ---- has_parallax on the slots whose key-frame test fired -----------------------------------------------------------
+  // Persistent workgroups over a slot queue, as many as the host FORECASTS tests from the results of the step collected last
+  // (should_add_keyframe's count / observation rules are known one frame ahead; the motion rule is not: a slot the
+  // forecast missed is solved by the same workgroups a little later, never skipped).  The H workgroup needs 138 KB of
+  // LDS, i.e. an empty CU: one workgroup per slot cost 1.4 + 1.8 ms of stream time on the ten steps in eleven where no slot
+  // of the context tests at all.
+  int hf_grid = B;
+  if (t->res_valid && t->policy != 1) {
+    int fc = 0;
+    const long long ahead = 1 + t->npending;   // frames between the results in hand and the step being enqueued
+    for (int s = 0; s < B; s++) {
+      const mvo_step_result& r = t->last_res[s];
+      fc += r.state == MVO_TRACK_TRACKING && ((long long)r.tracking_count + ahead > (long long)c.max_tracking_after_keyframe ||
+                                                (long long)r.n_tracks < (long long)c.min_observations_before_triangulation);
+    }
+    hf_grid = t->policy == 2 ? 8 : fc + 8 + fc / 8;
+  }
   { ProfScope ps(ctx, "ransac_h");
-    geom_ransac_h(ctx, B, p->d_cur_kf, p->d_cur_pts, t->d_n_hf, c.ransac_reproj_thresh, 2000, 0.995, g->d_mask2, g->d_model2, g->d_result2, st); }
+    geom_ransac_h(ctx, B, p->d_cur_kf, p->d_cur_pts, t->d_n_hf, c.ransac_reproj_thresh, 2000, 0.995, g->d_mask2, g->d_model2, g->d_result2, st,
+                  t->d_hf_ctr, hf_grid); }
   { ProfScope ps(ctx, "ransac_f");
-    geom_ransac_f(ctx, B, p->d_cur_kf, p->d_cur_pts, t->d_n_hf, c.ransac_reproj_thresh, 1000, 0.99, t->d_mask_f, t->d_model_f, t->d_result_f, st); }
+    geom_ransac_f(ctx, B, p->d_cur_kf, p->d_cur_pts, t->d_n_hf, c.ransac_reproj_thresh, 1000, 0.99, t->d_mask_f, t->d_model_f, t->d_result_f, st,
+                  t->d_hf_ctr + 1, hf_grid); }
   hipLaunchKernelGGL(trk_policy_parallax_kernel, dim3(1), dim3(1024), 0, st, t->d_n_hf, g->d_result2, t->d_result_f, B, c.f_inlier_thresh,
                      c.model_score_thresh, t->policy, t->d_flags, t->d_res, t->d_kf_list, t->d_nkf);
   // ---- add_new_keyframe over the key-frame list --------------------------------------------------------------------------
@@ -803,9 +838,10 @@ static int trk_step_enqueue(mvo_ctx* ctx, int frame_idx) {
   if (t->out_on)
     hipLaunchKernelGGL(trk_output_kernel, dim3(nb), dim3(256), 0, st, t->d_state, t->d_flags, g->d_pose, B, t->d_ros, t->d_path, t->d_n_path,
                        t->path_cap, t->d_err);
-  MVO_HIP(hipMemcpyAsync(t->h_res, t->d_res, (size_t)B * sizeof(mvo_step_result), hipMemcpyDeviceToHost, st));
-  MVO_HIP(hipMemcpyAsync(t->h_err, t->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
-  MVO_HIP(hipEventRecord(t->ev_done, st));
+  const int rb = (t->head + t->npending) % TRK_DEPTH;   // result buffer of this step
+  MVO_HIP(hipMemcpyAsync(t->h_res[rb], t->d_res, (size_t)B * sizeof(mvo_step_result), hipMemcpyDeviceToHost, st));
+  MVO_HIP(hipMemcpyAsync(t->h_err[rb], t->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+  MVO_HIP(hipEventRecord(t->ev_done[rb], st));
   // this step's own reads of its frame (the key-frame branch's gather) are over at ev_rd[frame_idx]; the next step's LK launch
   // re-records it, since the entry is then the "prev" image
   MVO_HIP(hipEventRecord(p->ev_rd[frame_idx], st));
@@ -820,7 +856,7 @@ extern "C" int mvo_batch_track_async(mvo_ctx* ctx, int frame_idx) {
   int rc = trk_create(ctx);
   if (rc) return rc;
   TrackState* t = p->trk;
-  if (t->pending) { ctx->set_error("mvo_batch_track_async: the previous step has not been collected (mvo_batch_track_wait)"); return MVO_E_ARG; }
+  if (t->npending >= TRK_DEPTH) { ctx->set_error("mvo_batch_track_async: two steps are in flight already: collect the oldest first (mvo_batch_track_wait)"); return MVO_E_ARG; }
   if ((rc = trk_ring_events(ctx))) return rc;
   if (p->prev_entry < 0) {
     ctx->set_error("mvo_batch_track: the ring entry of the previous frame was overwritten before the next step (it is level 0 of the LK "
@@ -843,25 +879,29 @@ extern "C" int mvo_batch_track_async(mvo_ctx* ctx, int frame_idx) {
   }
   ctx->lk_cur ^= 1;
   p->prev_entry = frame_idx;
-  t->pending = true;
+  t->npending++;
   return MVO_OK;
 }
 
 // 1 when the step enqueued last has finished (mvo_batch_track_wait will not block), 0 while it runs.
 extern "C" int mvo_batch_track_poll(mvo_ctx* ctx) {
-  if (!ctx || !ctx->pipe || !ctx->pipe->trk || !ctx->pipe->trk->pending) return 1;
-  return hipEventQuery(ctx->pipe->trk->ev_done) == hipSuccess ? 1 : 0;
+  if (!ctx || !ctx->pipe || !ctx->pipe->trk || !ctx->pipe->trk->npending) return 1;
+  return hipEventQuery(ctx->pipe->trk->ev_done[ctx->pipe->trk->head]) == hipSuccess ? 1 : 0;
 }
 
 extern "C" int mvo_batch_track_wait(mvo_ctx* ctx, mvo_step_result* out) {
   if (!ctx || !ctx->pipe || !ctx->pipe->trk) return MVO_E_ARG;
   TrackState* t = ctx->pipe->trk;
-  if (!t->pending) { ctx->set_error("mvo_batch_track_wait: no step in flight"); return MVO_E_ARG; }
-  MVO_HIP(hipEventSynchronize(t->ev_done));
-  t->pending = false;
-  if (out) memcpy(out, t->h_res, (size_t)ctx->B * sizeof(mvo_step_result));
-  if (*t->h_err) {
-    const int e = *t->h_err;
+  if (!t->npending) { ctx->set_error("mvo_batch_track_wait: no step in flight"); return MVO_E_ARG; }
+  const int rb = t->head;
+  MVO_HIP(hipEventSynchronize(t->ev_done[rb]));
+  t->head = (t->head + 1) % TRK_DEPTH;
+  t->npending--;
+  t->res_valid = true;
+  memcpy(t->last_res, t->h_res[rb], (size_t)ctx->B * sizeof(mvo_step_result));
+  if (out) memcpy(out, t->last_res, (size_t)ctx->B * sizeof(mvo_step_result));
+  if (*t->h_err[rb]) {
+    const int e = *t->h_err[rb];
     ctx->set_error(std::string("mvo_batch_track: device capacity exceeded (") + ((e & TRK_ERR_KEYPOINTS) ? "key-points > max_points " : "") +
                    ((e & TRK_ERR_CAND) ? "FAST candidates " : "") + ((e & TRK_ERR_KPCAP) ? "dense key-points " : "") + ((e & TRK_ERR_MAPCAP) ? "landmark cloud / path capacity" : "") + ")");
     MVO_HIP(hipMemsetAsync(t->d_err, 0, sizeof(int), ctx->stream));
@@ -917,7 +957,7 @@ extern "C" int mvo_batch_enable_output(mvo_ctx* ctx, int map_capacity, int path_
   int rc = trk_create(ctx);
   if (rc) return rc;
   TrackState* t = ctx->pipe->trk;
-  if (t->pending) { ctx->set_error("mvo_batch_enable_output: a step is in flight"); return MVO_E_ARG; }
+  if (t->npending) { ctx->set_error("mvo_batch_enable_output: a step is in flight"); return MVO_E_ARG; }
   MVO_HIP(hipStreamSynchronize(ctx->stream));
   void* old[] = {t->d_cloud, t->d_n_cloud, t->d_path, t->d_n_path, t->d_ros};
   for (void* q : old) if (q) (void)hipFree(q);
@@ -1017,7 +1057,8 @@ int trk_sync_upload(mvo_ctx* ctx) {
 int trk_reset(mvo_ctx* ctx) {
   if (!ctx->pipe || !ctx->pipe->trk) return MVO_OK;
   TrackState* t = ctx->pipe->trk;
-  if (t->pending) { MVO_HIP(hipEventSynchronize(t->ev_done)); t->pending = false; }
+  while (t->npending) { MVO_HIP(hipEventSynchronize(t->ev_done[t->head])); t->head = (t->head + 1) % TRK_DEPTH; t->npending--; }
+  t->res_valid = false;
   MVO_HIP(hipMemsetAsync(t->d_state, 0, ctx->B * sizeof(int), ctx->stream));
   MVO_HIP(hipMemsetAsync(t->d_count, 0, ctx->B * sizeof(int), ctx->stream));
   MVO_HIP(hipMemsetAsync(t->d_err, 0, sizeof(int), ctx->stream));

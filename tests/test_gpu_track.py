@@ -164,6 +164,60 @@ def test_async_ingest_and_interleaved_contexts_match_the_synchronous_run():
             c.close()
 
 
+def test_two_steps_in_flight_match_the_synchronous_run():
+    """mvo_batch_track_async accepts a second step while the first still runs (the stream never waits for the host between
+    frames): a 3-entry pinned ring, uploads two frames ahead, two steps in flight, results collected oldest first - identical
+    to stepping synchronously over preloaded frames.  A third enqueue without a wait is refused."""
+    N, NF = 16, 1000
+    K = synth.default_K(TS.W, TS.H)
+    kinds = ("lateral", "fast", "cut")
+    data = [TS.stream(kind, N) for kind in kinds]
+    B = len(kinds)
+
+    def key(o):
+        return (o.n_prev, o.n_tracked, o.pnp_ok, o.n_pnp_inliers, o.score_h, o.score_f, o.n_keypoints, o.n_matches, o.n_triangulated,
+                o.state, o.flags, o.tracking_count, o.n_tracks, tuple(o.rvec), tuple(o.tvec))
+
+    def seed(ctx):
+        ctx.batch_set_intrinsics(K)
+        for s in range(B):
+            ctx.batch_preload_frame(s, 0, data[s][0][0])
+        ctx.batch_seed(0)
+        for s in range(B):
+            ctx.batch_set_landmarks(s, TS.depth_landmarks(K, data[s][1])(ctx.batch_get_tracks(s)))
+
+    with Context(max_width=TS.W, max_height=TS.H, batch=B, nfeatures=NF, max_points=4096, ring_frames=N) as ctx:
+        seed(ctx)
+        for s in range(B):
+            for f in range(1, N):
+                ctx.batch_preload_frame(s, f, data[s][0][f])
+        want = [[key(o) for o in ctx.batch_track(k)] for k in range(1, N)]
+    RING = 3
+    with Context(max_width=TS.W, max_height=TS.H, batch=B, nfeatures=NF, max_points=4096, ring_frames=RING) as ctx:
+        seed(ctx)
+        pin = ctx.host_alloc(RING * B * TS.H * TS.W).reshape(RING, B, TS.H, TS.W)
+
+        def upload(k):
+            for s in range(B):
+                pin[k % RING, s] = data[s][0][k]
+            ctx.batch_upload_async(k % RING, pin[k % RING].ctypes.data, TS.W, TS.H, TS.W, TS.H * TS.W)
+        upload(1)
+        upload(2)
+        got, sent = [], 0
+        for k in (1, 2):
+            ctx.batch_track_async(k % RING)
+            sent = k
+        with pytest.raises(RuntimeError):
+            ctx.batch_track_async(0)                      # two in flight already
+        while len(got) < N - 1:
+            got.append([key(o) for o in ctx.batch_track_wait()])     # the oldest step
+            if sent + 1 < N:
+                sent += 1
+                upload(sent)                              # its entry was the LK template of the step collected just now
+                ctx.batch_track_async(sent % RING)
+        assert got == want
+
+
 def test_track_reproduces_the_committed_golden_vectors():
     """mvo_batch_track against tests/golden/track_v1.json (made by make_track_golden.py from the oracle-driven reference
     tracker): the fixtures, not a live oracle run, are the checker here."""
