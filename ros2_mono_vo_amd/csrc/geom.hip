@@ -484,17 +484,106 @@ struct PnpRefineArgs {
   CamK cam;
 };
 
-// One workgroup per stream.  Sums over the inlier set are block reductions in a fixed order (the oracle
-// sums sequentially, so R,t agree to rounding, not bit for bit); the small dense solves run on lane 0.
+// ---- wave-cooperative one-sided Jacobi SVD ------------------------------------------------------------------------------
+// The dense solves of the refine (12 x 12 DLT null vector, 6 x 6 Levenberg-Marquardt step) used to run on lane 0: 0.32 ms and
+// 3 x 0.03 ms of a 0.65 ms kernel for one stream (RS_TIMING), in ~1000 spilled registers.  Here a whole wavefront works on the
+// matrix in LDS.  JacobiSVDImpl_ (core/src/lapack.cpp; gl_jacobi_svd) visits the row pairs (i, j) of A^T one after the other;
+// pairs that share no row commute, so a sweep is re-ordered into the N - 1 rounds of a round-robin tournament, N / 2 disjoint
+// pairs each, and four pairs of a round are rotated AT ONCE, one per DPP row of 16 lanes: lane k of a row owns column k of
+// the two rows (their dot product and new norms are DPP row sums, the rotation itself is element-wise), and the scalar part
+// of a rotation (hypot, two square roots, the divisions - most of its instructions) is issued once for four pairs.  Same
+// rotation formulas, skip test and stopping rule as JacobiSVDImpl_; a different pair order, so singular vectors agree with the
+// sequential routine to rounding (the refine's contract is 1e-4 on R, t; measured against the oracle <= 1e-9), not bit for bit.
+template <int CTRL>
+__device__ __forceinline__ double wj_dpp(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+// sum over the 16 lanes of a DPP row, bit-identical in every lane of the row (each step adds the two halves of a disjoint split)
+__device__ __forceinline__ double wj_row_sum(double v) {
+  v += wj_dpp<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += wj_dpp<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += wj_dpp<0x141>(v);   // row_half_mirror
+  v += wj_dpp<0x140>(v);   // row_mirror
+  return v;
+}
+#define WJ_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+// At: N x N in LDS, row i = row i of A^T (= column i of A), overwritten by sigma_i * u_i^T; W: N doubles (LDS) -> sigma_i^2;
+// Vt: N x N (LDS) -> rows v_i^T.  All 64 lanes of ONE wavefront call it; N <= 16.
+template <int N>
+__device__ __forceinline__ void wave_jacobi_svd(double* At, double* W, double* Vt, const int lane) {
+  constexpr int NP = (N + 1) & ~1;   // players of the tournament (odd N: a dummy whose pairings are byes)
+  const double eps = DBL_EPSILON * 10;
+  const int row = lane >> 4, k = lane & 15;
+  const bool col = k < N;
+  for (int e = lane; e < N * N; e += 64) Vt[e] = (e / N == e % N) ? 1.0 : 0.0;
+  for (int i = row; i < N; i += 4) {
+    const double x = col ? At[i * N + k] : 0.0;
+    const double sd = wj_row_sum(x * x);
+    if (k == 0) W[i] = sd;
+  }
+  WJ_FENCE();
+  for (int iter = 0; iter < 30; iter++) {
+    bool changed = false;
+#pragma unroll 1
+    for (int r = 0; r < NP - 1; r++) {
+#pragma unroll 1
+      for (int q0 = 0; q0 < NP / 2; q0 += 4) {
+        const int q = q0 + row;
+        int i = q == 0 ? NP - 1 : (r + q) % (NP - 1);
+        int j = q == 0 ? r : (r - q + (NP - 1)) % (NP - 1);
+        if (i > j) { const int t = i; i = j; j = t; }
+        if (q < NP / 2 && j < N) {   // uniform over the row
+          const double ai = col ? At[i * N + k] : 0.0, aj = col ? At[j * N + k] : 0.0;
+          double p = wj_row_sum(ai * aj);
+          const double a = W[i], b = W[j];
+          if (!(fabs(p) <= eps * sqrt(a * b))) {
+            p *= 2;
+            const double beta = a - b, gamma = gl_hypot(p, beta);
+            double c, s;
+            if (beta < 0) {
+              const double delta = (gamma - beta) * 0.5;
+              s = sqrt(delta / gamma);
+              c = p / (gamma * s * 2);
+            } else {
+              c = sqrt((gamma + beta) / (gamma * 2));
+              s = p / (gamma * c * 2);
+            }
+            const double t0 = c * ai + s * aj, t1 = -s * ai + c * aj;
+            const double na = wj_row_sum(t0 * t0), nb = wj_row_sum(t1 * t1);
+            if (col) {
+              At[i * N + k] = t0; At[j * N + k] = t1;
+              const double vi = Vt[i * N + k], vj = Vt[j * N + k];
+              Vt[i * N + k] = c * vi + s * vj;
+              Vt[j * N + k] = -s * vi + c * vj;
+            }
+            if (k == 0) { W[i] = na; W[j] = nb; }
+            changed = true;
+          }
+        }
+        WJ_FENCE();   // the rows rotated by one DPP row are read by another in a later pass
+      }
+    }
+    if (!__any(changed)) break;
+  }
+}
+
+// One workgroup per stream: PR_T / 64 wavefronts.  Sums over the inlier set are block reductions in a fixed order (the oracle
+// sums sequentially, so R, t agree to rounding, not bit for bit); the dense solves are wave_jacobi_svd on wavefront 0.  The
+// accumulators of a pass over the points are at most 28 doubles per thread (the DLT normal matrix takes three passes): no
+// scratch, <= 128 VGPRs, so four of these wavefronts share a SIMD with anything.
 template <int PR_T>
 __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRefineArgs A) {
   constexpr int PR_NW = PR_T / 64;
-  __shared__ double s_red[PR_NW * 78];
-  __shared__ double s_sh[160];  // broadcast area
-  __shared__ double s_mat[2 * 144 + 16];  // lane-0 dense solves work in LDS, not in scratch (latency)
+  __shared__ double s_red[PR_NW * 28];
+  __shared__ double s_sh[64];       // broadcast area: Vt of the planarity test / the pose / dR/dr of an evaluation
+  __shared__ double s_mat[2 * 144 + 16];
   __shared__ int s_flag[4];
   __builtin_amdgcn_s_setprio(3);   // see ransac_kernel
-  const int slot = blockIdx.x, tid = threadIdx.x;
+  const int slot = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int* result = A.result + (size_t)slot * 8;
   double* pose = A.pose + (size_t)slot * 8;
   const int ok = result[0];
@@ -525,7 +614,6 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
 #endif
   double param[6] = {0, 0, 0, 0, 0, 0};
   // ---- Mc, MM ------------------------------------------------------------------------------------------------
-  double acc[45];
   double Mc[3];
   {
     double v[3] = {0, 0, 0};
@@ -589,35 +677,44 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
     }
     bool degenerate = fabs(s4[0]) < DBL_EPSILON || fabs(s4[1]) < DBL_EPSILON || fabs(s4[2]) < DBL_EPSILON || fabs(s4[3]) < DBL_EPSILON;
     double smx = count / s4[0], smy = count / s4[1], sMx = count / s4[2], sMy = count / s4[3];
-    double LtL[45];
-    {
-      for (int k = 0; k < 45; k++) acc[k] = 0;
-      if (!degenerate)
+    // LtL (9 x 9 symmetric, 45 sums) in three passes of 15 accumulators: rows 0-1, 2-4, 5-8 of the upper triangle
+    double* L = s_mat;
+    if (!degenerate) {
+#pragma unroll 1
+      for (int pass = 0; pass < 3; pass++) {
+        const int j0 = pass == 0 ? 0 : (pass == 1 ? 2 : 5), j1 = pass == 0 ? 2 : (pass == 1 ? 5 : 9);
+        double acc[18];
+        for (int k = 0; k < 18; k++) acc[k] = 0;
         for (int i = tid; i < count; i += PR_T) {
           double X, Y, x, y; mxy(i, X, Y); mnorm(i, x, y);
           x = (x - c4[0]) * smx; y = (y - c4[1]) * smy; X = (X - c4[2]) * sMx; Y = (Y - c4[3]) * sMy;
-          double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
-          double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
+          const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
+          const double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
           int q = 0;
+#pragma unroll
           for (int j = 0; j < 9; j++)
-            for (int k = j; k < 9; k++) acc[q++] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
+#pragma unroll
+            for (int k = j; k < 9; k++)
+              if (j >= j0 && j < j1) { acc[q] += Lx[j] * Lx[k] + Ly[j] * Ly[k]; q++; }
         }
-      block_sum<45, PR_NW>(acc, s_red, LtL);
+        double o[18];
+        block_sum<18, PR_NW>(acc, s_red, o);
+        if (tid == 0) {
+          int q = 0;
+          for (int j = j0; j < j1; j++)
+            for (int k = j; k < 9; k++) { L[j * 9 + k] = o[q]; L[k * 9 + j] = o[q]; q++; }
+        }
+      }
     }
+    __syncthreads();
     if (tid == 0) {
       double R[9];
       bool okH = !degenerate;
       double h[9];
       if (okH) {
-        double* L = s_mat;
         double* V = s_mat + 144;
-        double W[9];
-        int q = 0;
-        for (int j = 0; j < 9; j++)
-          for (int k = j; k < 9; k++) { L[j * 9 + k] = LtL[q]; L[k * 9 + j] = LtL[q]; q++; }
         gl_ldsd* Wl = (gl_ldsd*)(s_mat + 2 * 144);   // 9 of the 16 doubles behind the two matrices
         gl_jacobi_eigen9_lds<false>((gl_ldsd*)L, Wl, (gl_ldsd*)V);
-        for (int i = 0; i < 9; i++) W[i] = Wl[i];
         double invHnorm[9] = {1. / smx, 0, c4[0], 0, 1. / smy, c4[1], 0, 0, 1};
         double Hnorm2[9] = {sMx, 0, -c4[2] * sMx, 0, sMy, -c4[3] * sMy, 0, 0, 1};
         double Htemp[9], H0[9];
@@ -667,64 +764,67 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
     }
     // DLT normal matrix L^T L (12 x 12) with rows l0 = [P 0 x P], l1 = [0 P y P], P = [M 1]: of its 78 upper entries
     // block (0..3, 4..7) is zero, block (4..7, 4..7) repeats block (0..3, 0..3) term for term, and the others are sums of
-    // P_a P_b, P_a (x P_c), P_a (y P_c) and (x P_a)(x P_b) + (y P_a)(y P_b) - 52 accumulators instead of 78.  Same products,
-    // same order over the points; the reduced sums go straight into the LDS matrix.
+    // P_a P_b, P_a (x P_c), P_a (y P_c) and (x P_a)(x P_b) + (y P_a)(y P_b) - 52 sums, in three passes over the points of
+    // at most 20 accumulators each (same products, same order over the points as one pass).
     double* L = s_mat;
-    {
-      double A0[10], AX[16], AY[16], A2[10];
-      for (int k = 0; k < 10; k++) { A0[k] = 0; A2[k] = 0; }
-      for (int k = 0; k < 16; k++) { AX[k] = 0; AY[k] = 0; }
+#pragma unroll 1
+    for (int pass = 0; pass < 3; pass++) {
+      double acc[20];
+      for (int k = 0; k < 20; k++) acc[k] = 0;
       for (int i = tid; i < count; i += PR_T) {
         double M[3], m[2]; ptM(i, M); ptm(i, m);
         double xu, yu;
         gm_undistort_point(cam, m[0], m[1], xu, yu);
         const double x = -xu, y = -yu;
         const double P[4] = {M[0], M[1], M[2], 1.};
-        const double xP[4] = {x * M[0], x * M[1], x * M[2], x}, yP[4] = {y * M[0], y * M[1], y * M[2], y};
-        int q = 0;
+        if (pass == 0) {
+          const double xP[4] = {x * M[0], x * M[1], x * M[2], x}, yP[4] = {y * M[0], y * M[1], y * M[2], y};
+          int q = 0;
 #pragma unroll
-        for (int a = 0; a < 4; a++) {
+          for (int a = 0; a < 4; a++)
 #pragma unroll
-          for (int b = a; b < 4; b++) { A0[q] += P[a] * P[b]; A2[q] += xP[a] * xP[b] + yP[a] * yP[b]; q++; }
+            for (int b = a; b < 4; b++) { acc[q] += P[a] * P[b]; acc[10 + q] += xP[a] * xP[b] + yP[a] * yP[b]; q++; }
+        } else {
+          const double w = pass == 1 ? x : y;
+          const double wP[4] = {w * M[0], w * M[1], w * M[2], w};
 #pragma unroll
-          for (int c = 0; c < 4; c++) { AX[4 * a + c] += P[a] * xP[c]; AY[4 * a + c] += P[a] * yP[c]; }
+          for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[4 * a + c] += P[a] * wP[c];
         }
       }
-      double o[16];
-      block_sum<10, PR_NW>(A0, s_red, o);
+      double o[20];
+      block_sum<20, PR_NW>(acc, s_red, o);
       if (tid == 0) {
-        int q = 0;
-        for (int a = 0; a < 4; a++)
-          for (int b = a; b < 4; b++) {
-            L[a * 12 + b] = o[q]; L[b * 12 + a] = o[q];
-            L[(4 + a) * 12 + 4 + b] = o[q]; L[(4 + b) * 12 + 4 + a] = o[q];
-            q++;
-          }
-        for (int a = 0; a < 4; a++)
-          for (int b = 0; b < 4; b++) { L[a * 12 + 4 + b] = 0; L[(4 + b) * 12 + a] = 0; }
-      }
-      block_sum<16, PR_NW>(AX, s_red, o);
-      if (tid == 0)
-        for (int a = 0; a < 4; a++)
-          for (int c = 0; c < 4; c++) { L[a * 12 + 8 + c] = o[4 * a + c]; L[(8 + c) * 12 + a] = o[4 * a + c]; }
-      block_sum<16, PR_NW>(AY, s_red, o);
-      if (tid == 0)
-        for (int a = 0; a < 4; a++)
-          for (int c = 0; c < 4; c++) { L[(4 + a) * 12 + 8 + c] = o[4 * a + c]; L[(8 + c) * 12 + 4 + a] = o[4 * a + c]; }
-      block_sum<10, PR_NW>(A2, s_red, o);
-      if (tid == 0) {
-        int q = 0;
-        for (int a = 0; a < 4; a++)
-          for (int b = a; b < 4; b++) { L[(8 + a) * 12 + 8 + b] = o[q]; L[(8 + b) * 12 + 8 + a] = o[q]; q++; }
+        if (pass == 0) {
+          int q = 0;
+          for (int a = 0; a < 4; a++)
+            for (int b = a; b < 4; b++) {
+              L[a * 12 + b] = o[q]; L[b * 12 + a] = o[q];
+              L[(4 + a) * 12 + 4 + b] = o[q]; L[(4 + b) * 12 + 4 + a] = o[q];
+              L[(8 + a) * 12 + 8 + b] = o[10 + q]; L[(8 + b) * 12 + 8 + a] = o[10 + q];
+              q++;
+            }
+          for (int a = 0; a < 4; a++)
+            for (int b = 0; b < 4; b++) { L[a * 12 + 4 + b] = 0; L[(4 + b) * 12 + a] = 0; }
+        } else {
+          const int r0 = pass == 1 ? 0 : 4;
+          for (int a = 0; a < 4; a++)
+            for (int c = 0; c < 4; c++) { L[(r0 + a) * 12 + 8 + c] = o[4 * a + c]; L[(8 + c) * 12 + r0 + a] = o[4 * a + c]; }
+        }
       }
     }
+    __syncthreads();
     PR_TICK(0)
+    double* LV = s_mat + 144;
+    double* LW = s_mat + 288;
+    // cvSVD(&_LL, &_LW, 0, &_LV, MODIFY_A + V_T): the right singular vector of the smallest singular value (L^T = L)
+    if (wave == 0) wave_jacobi_svd<12>(L, LW, LV, lane);
+    __syncthreads();
     if (tid == 0) {
-      double* LV = s_mat + 144;
-      double* LW = s_mat + 288;
-      // cvSVD(&_LL, &_LW, 0, &_LV, MODIFY_A + V_T): Vt; run the one-sided Jacobi on L^T (= L)
-      gl_jacobi_svd12_lds<true>((gl_lds_double*)L, (gl_lds_double*)LW, (gl_lds_double*)LV);
-      double* RRt = LV + 11 * 12;
+      int imin = 0;
+      for (int i = 1; i < 12; i++) if (LW[i] < LW[imin]) imin = i;
+      double* RRt = LV + imin * 12;
       double RR[9], ttv[3];
       for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) RR[r * 3 + c] = RRt[r * 4 + c]; ttv[r] = RRt[r * 4 + 3]; }
       if (gl_det3(RR) < 0) { for (int i = 0; i < 9; i++) RR[i] *= -1; for (int i = 0; i < 3; i++) ttv[i] *= -1; }
@@ -752,24 +852,45 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
   __syncthreads();
   PR_TICK(1)
 
-  // ---- CvLevMarq (J + err mode), state machine replicated by every lane, solves on lane 0 --------------------
+  // ---- CvLevMarq (J + err mode), state machine replicated by every lane, the 6 x 6 solve by wavefront 0 ---------------------
   enum { DONE = 0, STARTED = 1, CALC_J = 2, CHECK_ERR = 3 };
   int state = STARTED, iters = 0, lambdaLg10 = -3;
-  double prevParam[6], JtJ[21], JtErr[6], prevErrNorm = DBL_MAX, errNorm = 0, curErr2 = 0;
+  double prevParam[6], prevErrNorm = DBL_MAX, errNorm = 0, curErr2 = 0;
   const int max_iter = 20;
   const double epsilon = FLT_EPSILON;
+  // JtJ (upper triangle, 21) and JtErr (6) of the last CALC_J evaluation stay in LDS: s_mat[200 .. 227)
+  double* JJ = s_mat + 200;
   auto step = [&]() {
-    if (tid == 0) {
+    // cvSolve(JtJ + lambda diag(JtJ), JtErr, DECOMP_SVD): x = sum over sigma_i > threshold of (u_i . b / sigma_i) v_i
+    double* Am = s_mat;         // 6 x 6 -> sigma_i u_i^T
+    double* Vm = s_mat + 36;    // 6 x 6
+    double* Wm = s_mat + 72;    // sigma_i^2
+    if (wave == 0) {
       const double LOG10 = log(10.);
-      double lambda = exp(lambdaLg10 * LOG10);
-      double* Am = s_mat;
-      double x[6];
-      int q = 0;
-      for (int a = 0; a < 6; a++)
-        for (int b = a; b < 6; b++) { Am[a * 6 + b] = JtJ[q]; Am[b * 6 + a] = JtJ[q]; q++; }
-      for (int i = 0; i < 6; i++) Am[i * 6 + i] *= 1. + lambda;
-      if (!gl_solve_svd_fixed<6, 6>(Am, JtErr, x)) gl_solve_svd_ws(Am, 6, 6, JtErr, x, s_mat + 40, s_mat + 80);
-      for (int i = 0; i < 6; i++) s_sh[i] = prevParam[i] - x[i];
+      const double lambda = exp(lambdaLg10 * LOG10);
+      if (lane < 36) {
+        const int a = lane / 6, b = lane % 6;
+        const int lo = a < b ? a : b, hi = a < b ? b : a;
+        double v = JJ[lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];   // entry (lo, hi) of the packed upper triangle
+        if (a == b) v *= 1. + lambda;
+        Am[lane] = v;
+      }
+      WJ_FENCE();
+      wave_jacobi_svd<6>(Am, Wm, Vm, lane);
+      if (lane == 0) {
+        double sig[6], thr = 0;
+        for (int i = 0; i < 6; i++) { sig[i] = sqrt(Wm[i]); thr += sig[i]; }
+        thr *= DBL_EPSILON * 2;
+        double x[6] = {0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 6; i++) {
+          if (fabs(sig[i]) <= thr) continue;
+          double d = 0;
+          for (int j = 0; j < 6; j++) d += Am[i * 6 + j] * JJ[21 + j];
+          d /= Wm[i];                         // (sigma_i u_i . b) / sigma_i^2
+          for (int j = 0; j < 6; j++) x[j] += d * Vm[i * 6 + j];
+        }
+        for (int i = 0; i < 6; i++) s_sh[i] = prevParam[i] - x[i];
+      }
     }
     __syncthreads();
     for (int i = 0; i < 6; i++) param[i] = s_sh[i];
@@ -777,8 +898,12 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
     PR_TICK(2)
   };
   auto eval = [&](bool withJ) {
-    double R[9], dRdr[27];
-    gm_rodrigues_v2m(param, R, withJ ? dRdr : nullptr);
+    // R and dR/dr once per evaluation, through LDS (27 + 9 doubles are not worth 72 registers in every lane)
+    if (tid == 0) gm_rodrigues_v2m(param, s_sh + 8, withJ ? s_sh + 17 : nullptr);
+    __syncthreads();
+    double R[9];
+    for (int i = 0; i < 9; i++) R[i] = s_sh[8 + i];
+    const double* dRdr = s_sh + 17;
     double v[28];
     for (int k = 0; k < 28; k++) v[k] = 0;
     for (int i = tid; i < count; i += PR_T) {
@@ -799,13 +924,13 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
     double o[28];
     if (withJ) {
       block_sum<28, PR_NW>(v, s_red, o);
-      for (int k = 0; k < 21; k++) JtJ[k] = o[k];
-      for (int k = 0; k < 6; k++) JtErr[k] = o[21 + k];
+      if (tid == 0) for (int k = 0; k < 27; k++) JJ[k] = o[k];
       curErr2 = o[27];
     } else {
       block_sum<1, PR_NW>(v + 27, s_red, o);
       curErr2 = o[0];
     }
+    __syncthreads();   // JJ is complete / s_sh may be rewritten
     PR_TICK(3)
 #ifdef RS_TIMING
     pt[withJ ? 4 : 5] += 1;

@@ -273,7 +273,7 @@ def test_output_side_on_the_device_matches_the_node_bookkeeping():
     """SURVEY 8(f) rank 4 on the HIP path: with mvo_batch_enable_output every step ends with MonoVO::image_callback's pose
     bookkeeping per slot (src/mono_vo.cpp:117-152) - last_pose_ in REP-103 (src/utils.cpp:85-129), the path, and the Map as
     PointCloud2 payload (src/utils.cpp:190-243) in landmark-id order.  Checked against the host restatement (ros_io.py) fed
-    with the reference tracker's poses and Map (tests/track_ref.py over the oracle): seed cloud bytes identical, later landmarks within float32 rounding, poses <= 1e-9."""
+    with the reference tracker's poses and Map (tests/track_ref.py over the oracle): seed cloud bytes identical, later landmarks within float32 rounding, poses <= 2e-8 (contract 1e-4)."""
     from ros2_mono_vo_amd import ros_io
     import oracle_py as O
     N, NF = 26, 1000
@@ -317,7 +317,7 @@ def test_output_side_on_the_device_matches_the_node_bookkeeping():
                     paths[s].push(last[s][0], last[s][1], k)
                 pos, quat = ros_io.pose_cv_to_ros(*last[s])
                 assert bool(odo[s].tracking_valid) == valid[s] and odo[s].has_pose == 1
-                assert np.abs(np.array(odo[s].position) - pos).max() < 1e-9 and np.abs(np.array(odo[s].orientation) - quat).max() < 1e-9
+                assert np.abs(np.array(odo[s].position) - pos).max() < 2e-8 and np.abs(np.array(odo[s].orientation) - quat).max() < 2e-8
         for s, r in enumerate(refs):
             cloud = ctx.batch_get_pointcloud(s)
             want = ros_io.pointcloud2(r.map.get_landmark_points(), 0)
@@ -329,7 +329,7 @@ def test_output_side_on_the_device_matches_the_node_bookkeeping():
             path = ctx.batch_get_path(s)
             assert len(path) == len(paths[s].poses)
             for a, b in zip(path, paths[s].poses):
-                assert np.abs(a[:3] - b["position"]).max() < 1e-9 and np.abs(a[3:] - b["orientation"]).max() < 1e-9
+                assert np.abs(a[:3] - b["position"]).max() < 2e-8 and np.abs(a[3:] - b["orientation"]).max() < 2e-8
         # every seed observation has a landmark, so a slot's FIRST key-frame adds none; the fast mover's later ones do
         assert grew[1] and not valid[2] and len(paths[2].poses) < N - 1 == len(paths[1].poses)   # ... and the cut stream went LOST
 
