@@ -304,67 +304,107 @@ __device__ __forceinline__ void ransac_slot(const RansacArgs& A, const int slot)
     }
     __syncthreads();
     RS_TICK(2)
+    // ---- 4 + 5 (M::SEQ_SCORE): score and replay hypothesis by hypothesis --------------------------------------------------
+    // solvePnPRansac's loop usually ends after a handful of iterations (RANSACUpdateNumIters on the first good model), so
+    // scoring all of a round's hypotheses first - each over every point - is mostly wasted: 188 of 963 us for one stream of
+    // 2000 correspondences (RS_TIMING).  Here all threads score ONE hypothesis, lane 0 applies OpenCV's update, and the loop
+    // stops where OpenCV's does.  Same counts, same order, same result.
+    if constexpr (M::SEQ_SCORE) {
+      static_assert(NW == 1 && M::MAXM == 1 && M::LMEDS_BELOW == 0, "sequential scoring is a single-wave, single-model mode");
+      for (int h = 0; h < nsolve; h++) {
+        if (s_ctl[3] >= s_ctl[4]) break;   // iter >= niters (uniform: read after the fence below)
+        if (s_nmodels[h] > 0) {
+          typename M::Scorer sc;
+          sc.init(A.P, &s_models[h][0][0]);
+          int good = 0;
+#pragma unroll 1
+          for (int i = tid; i < count; i += RS_TT) good += sc.err(m1 + (size_t)i * M::PT1, m2 + (size_t)i * M::PT2) <= t;
+          if (good) atomicAdd(&s_cnt[h][0], good);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (tid == 0) {
+          int maxGood = s_ctl[2], niters = s_ctl[4];
+          if (s_nmodels[h] > 0) {
+            const int good = s_cnt[h][0];
+            s_ctl[7]++;
+            if (good > max(maxGood, M::MP - 1)) {
+              for (int k = 0; k < M::MS; k++) s_best[k] = s_models[h][0][k];
+              maxGood = good;
+              niters = gl_ransac_update_num_iters(A.conf, (double)(count - good) / count, M::MP, niters);
+            }
+          }
+          s_ctl[2] = maxGood; s_ctl[4] = niters; s_ctl[3]++;
+          if (s_ctl[3] >= niters) s_ctl[1] = 1;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      __syncthreads();
+      RS_TICK(3)
+    } else {
     // ---- 4. scoring: hypothesis = tid % RS_CH, point partition = tid / RS_CH; integer inlier counts ------------
-    {
-      const int parts = RS_TT / ch, hyp = tid % ch, part = tid / ch;
-      if (lmeds) {
-        if (part == 0 && hyp < nsolve) {
+      {
+        const int parts = RS_TT / ch, hyp = tid % ch, part = tid / ch;
+        if (lmeds) {
+          if (part == 0 && hyp < nsolve) {
+            const int nmh = s_nmodels[hyp];
+            for (int q = 0; q < nmh; q++) {
+              typename M::Scorer sc;
+              sc.init(A.P, &s_models[hyp][q][0]);
+              // median = element count/2 of the sorted errors (count < 15: insertion sort in registers / private memory)
+              float e[16];
+  #pragma unroll 1
+              for (int i = 0; i < count; i++) {
+                float v = sc.err(m1 + (size_t)i * M::PT1, m2 + (size_t)i * M::PT2);
+                int k = i;
+                while (k > 0 && e[k - 1] > v) { e[k] = e[k - 1]; --k; }
+                e[k] = v;
+              }
+              s_cnt[hyp][q] = __float_as_int(e[count / 2]);
+            }
+          }
+        } else if (hyp < nsolve && part < parts) {   // lanes past parts * ch (ch not a divisor of 64) sit the scoring out
           const int nmh = s_nmodels[hyp];
           for (int q = 0; q < nmh; q++) {
             typename M::Scorer sc;
             sc.init(A.P, &s_models[hyp][q][0]);
-            // median = element count/2 of the sorted errors (count < 15: insertion sort in registers / private memory)
-            float e[16];
-#pragma unroll 1
-            for (int i = 0; i < count; i++) {
-              float v = sc.err(m1 + (size_t)i * M::PT1, m2 + (size_t)i * M::PT2);
-              int k = i;
-              while (k > 0 && e[k - 1] > v) { e[k] = e[k - 1]; --k; }
-              e[k] = v;
-            }
-            s_cnt[hyp][q] = __float_as_int(e[count / 2]);
+            int good = 0;
+  #pragma unroll 1
+            for (int i = part; i < count; i += parts) good += sc.err(m1 + (size_t)i * M::PT1, m2 + (size_t)i * M::PT2) <= t;
+            atomicAdd(&s_cnt[hyp][q], good);
           }
         }
-      } else if (hyp < nsolve && part < parts) {   // lanes past parts * ch (ch not a divisor of 64) sit the scoring out
-        const int nmh = s_nmodels[hyp];
-        for (int q = 0; q < nmh; q++) {
-          typename M::Scorer sc;
-          sc.init(A.P, &s_models[hyp][q][0]);
-          int good = 0;
-#pragma unroll 1
-          for (int i = part; i < count; i += parts) good += sc.err(m1 + (size_t)i * M::PT1, m2 + (size_t)i * M::PT2) <= t;
-          atomicAdd(&s_cnt[hyp][q], good);
-        }
       }
-    }
-    __syncthreads();
-    RS_TICK(3)
-    // ---- 5. ordered replay of OpenCV's consensus update -------------------------------------------------------
-    if (tid == 0) {
-      int maxGood = s_ctl[2], iter = s_ctl[3], niters = s_ctl[4], scored = s_ctl[7];
-      for (int h = 0; h < nsolve && iter < niters; h++, iter++) {
-        int nmh = s_nmodels[h];
-        for (int q = 0; q < nmh; q++) {
-          int good = s_cnt[h][q];
-          scored++;
-          if (lmeds) {
-            const double median = (double)__int_as_float(good);
-            if (median < s_minmed) {
-              s_minmed = median;
+      __syncthreads();
+      RS_TICK(3)
+      // ---- 5. ordered replay of OpenCV's consensus update -------------------------------------------------------
+      if (tid == 0) {
+        int maxGood = s_ctl[2], iter = s_ctl[3], niters = s_ctl[4], scored = s_ctl[7];
+        for (int h = 0; h < nsolve && iter < niters; h++, iter++) {
+          int nmh = s_nmodels[h];
+          for (int q = 0; q < nmh; q++) {
+            int good = s_cnt[h][q];
+            scored++;
+            if (lmeds) {
+              const double median = (double)__int_as_float(good);
+              if (median < s_minmed) {
+                s_minmed = median;
+                for (int k = 0; k < M::MS; k++) s_best[k] = s_models[h][q][k];
+              }
+            } else if (good > max(maxGood, M::MP - 1)) {
               for (int k = 0; k < M::MS; k++) s_best[k] = s_models[h][q][k];
+              maxGood = good;
+              niters = gl_ransac_update_num_iters(A.conf, (double)(count - good) / count, M::MP, niters);
             }
-          } else if (good > max(maxGood, M::MP - 1)) {
-            for (int k = 0; k < M::MS; k++) s_best[k] = s_models[h][q][k];
-            maxGood = good;
-            niters = gl_ransac_update_num_iters(A.conf, (double)(count - good) / count, M::MP, niters);
           }
         }
+        s_ctl[2] = maxGood; s_ctl[3] = iter; s_ctl[4] = niters; s_ctl[7] = scored;
+        if (iter >= niters) s_ctl[1] = 1;
       }
-      s_ctl[2] = maxGood; s_ctl[3] = iter; s_ctl[4] = niters; s_ctl[7] = scored;
-      if (iter >= niters) s_ctl[1] = 1;
+      __syncthreads();
+      RS_TICK(4)
     }
-    __syncthreads();
-    RS_TICK(4)
     if (s_ctl[1]) break;
     if (M::OVERDRAW) {   // the candidates solved leave the queue, the others move up (read, barrier, write: ranges overlap)
       const int left = npass - nsolve;

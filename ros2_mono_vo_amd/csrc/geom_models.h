@@ -45,6 +45,7 @@ struct ModelParams { CamK cam; };
 #define RS_H_OVERDRAW 1
 #endif
 struct HModel {
+  static constexpr bool SEQ_SCORE = false;   // score all hypotheses of a round, then replay (geom.hip)
   static constexpr int MP = 4, MAXM = 1, MS = 9, PT1 = 2, PT2 = 2;
   // 16 hypotheses per round, every round in LDS (16 x 193 doubles = 25 KB): a 64-wide round with 48 workspaces in
   // private memory took 2.85 ms against 0.8 ms for an LDS round, i.e. more per hypothesis; wider LDS rounds (24, 32)
@@ -159,6 +160,7 @@ struct HModel {
 // Fundamental matrix, 7 points (FMEstimatorCallback / run7Point)
 // ---------------------------------------------------------------------------------------------------
 struct FModel {
+  static constexpr bool SEQ_SCORE = false;   // score all hypotheses of a round, then replay (geom.hip)
   static constexpr int MP = 7, MAXM = 3, MS = 9, PT1 = 2, PT2 = 2;
   static constexpr int CH = 16, WS = 63 + 81 + 81 + 49;  // a, v, ta, tv
   static constexpr bool WIDE = true;
@@ -951,8 +953,17 @@ __device__ GL_NOINLINE double ep_compute_R_and_t(EpnpState& e, const double* ut,
 // solvePnP(SOLVEPNP_EPNP) for 5 float correspondences -> rvec, tvec
 // ws: 288 doubles.  [0,144) MtM, rotated in place into Ut by the SVD; [144,276) first M (2n x 12 = 120), then dv (72) + L (60) and,
 // over the dead dv, the workspaces of the three small least-squares solves; [276,288) singular values.
+#ifdef EP_TIMING
+__device__ long long g_ep_ticks[8];
+#define EP_TICK(k) { long long tn_ = wall_clock64(); if (threadIdx.x == 0 && blockIdx.x == 0) g_ep_ticks[k] += tn_ - tq_; tq_ = tn_; }
+#else
+#define EP_TICK(k)
+#endif
 __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const CamK& cam, double rvec[3], double tvec[3], double* ws) {
   const int n = EP_N;
+#ifdef EP_TIMING
+  long long tq_ = wall_clock64();
+#endif
   EpnpState e;
   e.fu = cam.fx; e.fv = cam.fy; e.uc = cam.cx; e.vc = cam.cy;
   for (int i = 0; i < n; i++) {
@@ -999,6 +1010,7 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
       a[0] = 1.0f - a[1] - a[2] - a[3];
     }
   }
+  EP_TICK(0)
   // M (2n x 12), MtM, SVD
   double* ut = ws;
   double* ws2 = ws + 144;
@@ -1030,6 +1042,7 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
     if (gl_is_lds(ws)) gl_jacobi_svd12_lds<false>((gl_lds_double*)mtm, (gl_lds_double*)(ws + 276), nullptr);
     else gl_jacobi_svd(mtm, 12, d, nullptr, 12, 12, 12, true);
   }
+  EP_TICK(1)
   // dv (4 x 6 x 3) and L_6x10 live in the workspace (the V block is free after the SVD) and their loops stay rolled:
   // as register arrays they pushed this function to ~250 VGPRs
   double* dvm = ws2;         // [4][6][3], dead once L is built
@@ -1068,6 +1081,7 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
     rho[0] = ep_dist2(e.cws[0], e.cws[1]); rho[1] = ep_dist2(e.cws[0], e.cws[2]); rho[2] = ep_dist2(e.cws[0], e.cws[3]);
     rho[3] = ep_dist2(e.cws[1], e.cws[2]); rho[4] = ep_dist2(e.cws[1], e.cws[3]); rho[5] = ep_dist2(e.cws[2], e.cws[3]);
   }
+  EP_TICK(2)
   double Betas[4][4], rep_errors[4] = {0, 0, 0, 0};
   double Rs[4][3][3], ts[4][3];
   {  // find_betas_approx_1
@@ -1078,8 +1092,11 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
     if (b4[0] < 0) { betas[0] = sqrt(-b4[0]); betas[1] = -b4[1] / betas[0]; betas[2] = -b4[2] / betas[0]; betas[3] = -b4[3] / betas[0]; }
     else { betas[0] = sqrt(b4[0]); betas[1] = b4[1] / betas[0]; betas[2] = b4[2] / betas[0]; betas[3] = b4[3] / betas[0]; }
   }
+  EP_TICK(3)
   ep_gauss_newton(l_6x10, rho, Betas[1]);
+  EP_TICK(4)
   rep_errors[1] = ep_compute_R_and_t(e, ut, Betas[1], Rs[1], ts[1]);
+  EP_TICK(5)
   {  // find_betas_approx_2
     double l[18], b3[3];
     for (int i = 0; i < 6; i++) { l[i * 3] = l_6x10[i * 10]; l[i * 3 + 1] = l_6x10[i * 10 + 1]; l[i * 3 + 2] = l_6x10[i * 10 + 2]; }
@@ -1106,6 +1123,7 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
   }
   ep_gauss_newton(l_6x10, rho, Betas[3]);
   rep_errors[3] = ep_compute_R_and_t(e, ut, Betas[3], Rs[3], ts[3]);
+  EP_TICK(6)
   int N = 1;
   if (rep_errors[2] < rep_errors[1]) N = 2;
   if (rep_errors[3] < rep_errors[N]) N = 3;
@@ -1115,6 +1133,12 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
     for (int j = 0; j < 3; j++) R[i * 3 + j] = Rs[N][i][j];
   }
   gm_rodrigues_m2v(R, rvec);
+  EP_TICK(7)
+#ifdef EP_TIMING
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    printf("EP_TIMING prep %lld mtm+svd12 %lld L %lld approx1 %lld gn1 %lld Rt1 %lld approx2,3 %lld final %lld (100MHz ticks, cumulative)\n", g_ep_ticks[0], g_ep_ticks[1],
+           g_ep_ticks[2], g_ep_ticks[3], g_ep_ticks[4], g_ep_ticks[5], g_ep_ticks[6], g_ep_ticks[7]);
+#endif
 }
 
 #ifndef RS_PNP_CH
@@ -1122,6 +1146,7 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
                        // 1.53 ms at 2-20 % outliers (one round: latency bound whatever the width), 4.2 / 3.2 / 2.5 ms at 40 % (fewer rounds)
 #endif
 struct PnPModel {
+  static constexpr bool SEQ_SCORE = true;    // score + replay hypothesis by hypothesis: the loop usually ends after a few
   static constexpr int MP = 5, MAXM = 1, MS = 6, PT1 = 3, PT2 = 2;
   // Every round is 20 wide with the workspaces in LDS (20 x 289 doubles = 46 KB): a round is latency bound, ~0.85 ms
   // whatever its width, while a 64-wide round with 48 workspaces in private memory took 3.8 ms - more per hypothesis
@@ -1383,6 +1408,7 @@ __device__ GL_NOINLINE int em_solve5(const double* q1, const double* q2, double*
 }
 
 struct EModel {
+  static constexpr bool SEQ_SCORE = false;   // score all hypotheses of a round, then replay (geom.hip)
   static constexpr int MP = 5, MAXM = 10, MS = 9, PT1 = 2, PT2 = 2;
   static constexpr int CH = 64, WS = 0;  // initialisation only (src/initializer.cpp), not on the per-frame path: private memory
   static constexpr bool WIDE = true;
