@@ -1142,7 +1142,7 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
 }
 
 #ifndef RS_PNP_CH
-#define RS_PNP_CH 20   // EPnP hypotheses per round.  One stream (profiles/tools/pnp_wall.py, RANSAC + refine): 16 / 20 / 32 wide 1.51 / 1.47 /
+#define RS_PNP_CH 12   // EPnP hypotheses per round (20 until round 3: in the bench 12 is +4 %: 28 KB of LDS per stream instead of 46 beside other contexts' LK).  One stream (profiles/tools/pnp_wall.py, RANSAC + refine): 16 / 20 / 32 wide 1.51 / 1.47 /
                        // 1.53 ms at 2-20 % outliers (one round: latency bound whatever the width), 4.2 / 3.2 / 2.5 ms at 40 % (fewer rounds)
 #endif
 struct PnPModel {
