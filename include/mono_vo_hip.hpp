@@ -492,7 +492,12 @@ class Tracker {
   Tracker(Map::Ptr map, FeatureProcessor::Ptr fp, TrackerParams p = {}) : map_(std::move(map)), fp_(std::move(fp)), p_(p) {}
   TrackerState get_state() const { return state_; }
   void reset() { state_ = TrackerState::INITIALIZING; }
-  struct Last { int n_tracked = 0, n_pnp_inliers = 0, score_h = 0, score_f = 0, n_keypoints = 0, n_matches = 0, n_triangulated = 0; } last;
+  struct Last {
+    int n_tracked = 0, n_pnp_inliers = 0, score_h = 0, score_f = 0, n_keypoints = 0, n_matches = 0, n_triangulated = 0;
+    bool pnp_ran = false, pnp_ok = false, kf_checked = false, keyframe_added = false;   // what the frame did (mvo_step_result.flags)
+  } last;
+  long tracking_count_from_keyframe() const { return tracking_count_from_keyframe_; }
+  const Frame& prev_frame() const { return prev_frame_; }
 
   Frame track_frame_with_optical_flow(const Image& new_image) {   // src/tracker.cpp:58-90
     Frame nf(new_image);
@@ -525,7 +530,7 @@ class Tracker {
     const auto p1 = map_->get_last_keyframe()->get_points_2d_for_landmarks(f.landmark_id);
     const auto p2 = f.get_points_2d();
     const auto r = check_parallax_impl(*fp_->backend, p1, p2, p_.ransac_reproj_thresh, p_.f_inlier_thresh, p_.model_score_thresh);
-    last.score_h = r.score_h; last.score_f = r.score_f;
+    last.score_h = r.score_h; last.score_f = r.score_f; last.kf_checked = true;
     return r.ok;
   }
   std::vector<Point3f> triangulate_points(const Affine3d& ref_cw, const Affine3d& cur_cw, const Mat3& K, const std::vector<Point2f>& ref, const std::vector<Point2f>& cur,
@@ -573,7 +578,7 @@ class Tracker {
       }
     map_->add_keyframe(map_->new_keyframe(f));
     tracking_count_from_keyframe_ = 0;
-    last.n_keypoints = (int)f.size(); last.n_matches = (int)good.size(); last.n_triangulated = (int)pts3d.size();
+    last.n_keypoints = (int)f.size(); last.n_matches = (int)good.size(); last.n_triangulated = (int)pts3d.size(); last.keyframe_added = true;
   }
   std::optional<Affine3d> update(const Frame& frame, const Mat3& K, const double d[5]) {   // src/tracker.cpp:274-333
     if (state_ == TrackerState::LOST) return std::nullopt;
@@ -585,7 +590,9 @@ class Tracker {
     std::vector<Point2f> p2; std::vector<Point3f> p3;
     map_->get_observation_to_landmark_point_correspondences(nf, p2, p3);
     double rvec[3], tvec[3];
-    if (!fp_->backend->solve_pnp_ransac(p3, p2, K, d, rvec, tvec, last.n_pnp_inliers)) {
+    last.pnp_ran = true;
+    last.pnp_ok = fp_->backend->solve_pnp_ransac(p3, p2, K, d, rvec, tvec, last.n_pnp_inliers);
+    if (!last.pnp_ok) {
       // the reference ignores the return value and reads an uninitialised rvec (undefined pose); defined here as in
       // include/mvo.h (MVO_STEP_PNP_FAILED): no pose for the frame, the count advances, the survivors carry on
       tracking_count_from_keyframe_++;

@@ -1,4 +1,5 @@
-"""Randomized campaign, run by hand on a GPU box (not collected by pytest): `python3 tests/fuzz_device_vs_oracle.py SEED`.
+"""Randomized campaign: `python3 tests/fuzz_device_vs_oracle.py SEED` by hand on a GPU box (four minutes), and a short seed of it
+under `-m gpu` (tests/test_gpu_fuzz_short.py).
 Four minutes of random small problems, the HIP path through the C ABI against the oracle: LK with random group sizes and
 mixes of interior / border / outside points, findHomography (masks and H bit for bit), findFundamentalMat (masks),
 solvePnPRansac incl. n = 4 / 5 / 6 (inlier lists bit for bit, poses to 1e-6).  Exit code 1 on any mismatch.
@@ -12,94 +13,105 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))   # te
 import numpy as np
 import oracle_py as O
 from ros2_mono_vo_amd import Context, synth
-t0 = time.time()
-rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
-bad = 0
-with Context(max_width=640, max_height=480, max_points=8192) as ctx:
-    fr = synth.gen_stream(640, 480, 0x5EED0042, 4)
-    k, _ = O.orb_detect_and_compute(fr[0], 1000)
-    good = np.stack([k["x"], k["y"]], 1).astype(np.float32)
-    n_lk = n_h = n_f = n_p = 0
-    while time.time() - t0 < 180:
-        # ---- LK: random group sizes, random mix of good / border / outside / sub-pixel points, random frame pair
-        n = int(rng.integers(1, 40))
-        pts = good[rng.choice(len(good), n)].copy() + rng.uniform(-0.5, 0.5, (n, 2)).astype(np.float32)
-        m = int(rng.integers(0, n + 1))
-        pos = rng.choice(n, m, replace=False)
-        pts[pos] = np.stack([rng.uniform(-40, 680, m), rng.uniform(-40, 520, m)], 1).astype(np.float32)
-        a, b = fr[int(rng.integers(0, 2))], fr[int(rng.integers(2, 4))]
-        gp, gs, ge = ctx.lk_track(a, b, pts)
-        op, os_, oe = O.lk_track(a, b, pts, cn=3)
-        if not (np.array_equal(gp, op) and np.array_equal(gs, os_) and np.array_equal(ge, oe)):
-            bad += 1; print("LK MISMATCH", n, m, flush=True)
-        n_lk += 1
-        # ---- geometry on random scenes
-        P = int(rng.integers(8, 400)); outl = float(rng.choice([0.0, 0.1, 0.3, 0.6])); planar = bool(rng.integers(0, 2))
-        sc = synth.gen_scene(P, int(rng.integers(0, 2**31)), planar=planar, outlier_frac=outl)
-        ok, mask, H, ni = ctx.find_homography_ransac(sc["p1"], sc["p2"], 1.0)
-        r, omask, oH, st = O.find_homography_ransac(sc["p1"], sc["p2"], 1.0, 2000, 0.995)
-        if not (ok == (r > 0) and np.array_equal(mask, omask) and (not ok or np.array_equal(H, oH))):
-            bad += 1; print("H MISMATCH", P, outl, planar, flush=True)
-        n_h += 1
-        if P >= 15:
-            ok, mask, F, ni = ctx.find_fundamental_ransac(sc["p1"], sc["p2"], 1.0, 0.99)
-            r, omask, oF, st = O.find_fundamental_ransac(sc["p1"], sc["p2"], 1.0, 0.99, 1000)
+
+
+def run(seed=1, seconds_a=180, seconds_b=60, verbose=True):
+    """-> (counts dict, mismatches)."""
+    t0 = time.time()
+    rng = np.random.default_rng(seed)
+    bad = 0
+    with Context(max_width=640, max_height=480, max_points=8192) as ctx:
+        fr = synth.gen_stream(640, 480, 0x5EED0042, 4)
+        k, _ = O.orb_detect_and_compute(fr[0], 1000)
+        good = np.stack([k["x"], k["y"]], 1).astype(np.float32)
+        n_lk = n_h = n_f = n_p = 0
+        while time.time() - t0 < seconds_a:
+            # ---- LK: random group sizes, random mix of good / border / outside / sub-pixel points, random frame pair
+            n = int(rng.integers(1, 40))
+            pts = good[rng.choice(len(good), n)].copy() + rng.uniform(-0.5, 0.5, (n, 2)).astype(np.float32)
+            m = int(rng.integers(0, n + 1))
+            pos = rng.choice(n, m, replace=False)
+            pts[pos] = np.stack([rng.uniform(-40, 680, m), rng.uniform(-40, 520, m)], 1).astype(np.float32)
+            a, b = fr[int(rng.integers(0, 2))], fr[int(rng.integers(2, 4))]
+            gp, gs, ge = ctx.lk_track(a, b, pts)
+            op, os_, oe = O.lk_track(a, b, pts, cn=3)
+            if not (np.array_equal(gp, op) and np.array_equal(gs, os_) and np.array_equal(ge, oe)):
+                bad += 1; print("LK MISMATCH", n, m, flush=True)
+            n_lk += 1
+            # ---- geometry on random scenes
+            P = int(rng.integers(8, 400)); outl = float(rng.choice([0.0, 0.1, 0.3, 0.6])); planar = bool(rng.integers(0, 2))
+            sc = synth.gen_scene(P, int(rng.integers(0, 2**31)), planar=planar, outlier_frac=outl)
+            ok, mask, H, ni = ctx.find_homography_ransac(sc["p1"], sc["p2"], 1.0)
+            r, omask, oH, st = O.find_homography_ransac(sc["p1"], sc["p2"], 1.0, 2000, 0.995)
+            if not (ok == (r > 0) and np.array_equal(mask, omask) and (not ok or np.array_equal(H, oH))):
+                bad += 1; print("H MISMATCH", P, outl, planar, flush=True)
+            n_h += 1
+            if P >= 15:
+                ok, mask, F, ni = ctx.find_fundamental_ransac(sc["p1"], sc["p2"], 1.0, 0.99)
+                r, omask, oF, st = O.find_fundamental_ransac(sc["p1"], sc["p2"], 1.0, 0.99, 1000)
+                if not (ok == (r > 0) and np.array_equal(mask, omask)):
+                    bad += 1; print("F MISMATCH", P, outl, planar, flush=True)
+                n_f += 1
+            npnp = int(rng.choice([4, 5, 6, 7, 12, P]))
+            idx = rng.choice(P, min(npnp, P), replace=False)
+            X, uv = sc["X"][idx], sc["p2"][idx]
+            try:
+                ok, rv, tv, inl = ctx.solve_pnp_ransac(X, uv, sc["K"])
+            except Exception as e:
+                ok, rv, tv, inl = None, None, None, None
+            rc, orv, otv, oidx, _ = O.solve_pnp_ransac(X, uv, sc["K"])
+            if ok is None:
+                if rc not in (-4,):   # the oracle's "DLT needs 6 points" abort is the only error the device may raise for
+                    bad += 1; print("PNP device raised, oracle rc", rc, len(idx), flush=True)
+            elif ok != (rc == 1) or (ok and not np.array_equal(inl, oidx)) or \
+                    (ok and np.linalg.norm(orv) < 3 and (np.abs(rv - orv).max() > 1e-6 * max(1, np.abs(orv).max()) or np.abs(tv - otv).max() > 1e-6 * max(1, np.abs(otv).max()))):
+                bad += 1; print("PNP MISMATCH n", len(idx), ok, rc, flush=True)
+            n_p += 1
+        # ---- second part (60 s): ORB on random crops / sizes, the matcher on random descriptors, E RANSAC + recoverPose + triangulation
+        n_orb = n_m = n_e = 0
+        base = synth.gen_stream(640, 480, 0x5EED0077, 1)[0]
+        t1 = time.time()
+        while time.time() - t1 < seconds_b:
+            w, h = int(rng.integers(64, 641)), int(rng.integers(64, 481))
+            x0, y0 = int(rng.integers(0, 641 - w)), int(rng.integers(0, 481 - h))
+            img = np.ascontiguousarray(base[y0:y0 + h, x0:x0 + w])
+            kps, desc = ctx.orb_detect_and_compute(img)
+            okps, odesc = O.orb_detect_and_compute(img, 1000)
+            if not (len(kps) == len(okps) and np.array_equal(desc, odesc) and all(np.array_equal(kps[f], okps[f]) for f in ("x", "y", "angle", "response", "octave"))):
+                bad += 1; print("ORB MISMATCH", w, h, x0, y0, len(kps), len(okps), flush=True)
+            n_orb += 1
+            nq, nt = int(rng.integers(0, 300)), int(rng.integers(0, 300))
+            q = rng.integers(0, 256, (nq, 32), dtype=np.uint8); t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+            if nq and nt >= 2 and rng.integers(0, 2):
+                t[rng.integers(0, nt)] = t[0]; q[0] = t[0]
+            ratio = float(rng.choice([0.5, 0.7, 0.9, 1.0]))
+            if not np.array_equal(ctx.match_knn2_ratio(q, t, ratio), O.match_knn2_ratio(q, t, ratio)):
+                bad += 1; print("MATCH MISMATCH", nq, nt, ratio, flush=True)
+            n_m += 1
+            P = int(rng.integers(5, 300)); outl = float(rng.choice([0.0, 0.1, 0.3]))
+            sc = synth.gen_scene(P, int(rng.integers(0, 2**31)), outlier_frac=outl)
+            ok, mask, E, ni = ctx.find_essential_ransac(sc["p1"], sc["p2"], sc["K"])
+            r, omask, oE, st = O.find_essential_ransac(sc["p1"], sc["p2"], sc["K"])
             if not (ok == (r > 0) and np.array_equal(mask, omask)):
-                bad += 1; print("F MISMATCH", P, outl, planar, flush=True)
-            n_f += 1
-        npnp = int(rng.choice([4, 5, 6, 7, 12, P]))
-        idx = rng.choice(P, min(npnp, P), replace=False)
-        X, uv = sc["X"][idx], sc["p2"][idx]
-        try:
-            ok, rv, tv, inl = ctx.solve_pnp_ransac(X, uv, sc["K"])
-        except Exception as e:
-            ok, rv, tv, inl = None, None, None, None
-        rc, orv, otv, oidx, _ = O.solve_pnp_ransac(X, uv, sc["K"])
-        if ok is None:
-            if rc not in (-4,):   # the oracle's "DLT needs 6 points" abort is the only error the device may raise for
-                bad += 1; print("PNP device raised, oracle rc", rc, len(idx), flush=True)
-        elif ok != (rc == 1) or (ok and not np.array_equal(inl, oidx)) or \
-                (ok and np.linalg.norm(orv) < 3 and (np.abs(rv - orv).max() > 1e-6 * max(1, np.abs(orv).max()) or np.abs(tv - otv).max() > 1e-6 * max(1, np.abs(otv).max()))):
-            bad += 1; print("PNP MISMATCH n", len(idx), ok, rc, flush=True)
-        n_p += 1
-    # ---- second part (60 s): ORB on random crops / sizes, the matcher on random descriptors, E RANSAC + recoverPose + triangulation
-    n_orb = n_m = n_e = 0
-    base = synth.gen_stream(640, 480, 0x5EED0077, 1)[0]
-    t1 = time.time()
-    while time.time() - t1 < 60:
-        w, h = int(rng.integers(64, 641)), int(rng.integers(64, 481))
-        x0, y0 = int(rng.integers(0, 641 - w)), int(rng.integers(0, 481 - h))
-        img = np.ascontiguousarray(base[y0:y0 + h, x0:x0 + w])
-        kps, desc = ctx.orb_detect_and_compute(img)
-        okps, odesc = O.orb_detect_and_compute(img, 1000)
-        if not (len(kps) == len(okps) and np.array_equal(desc, odesc) and all(np.array_equal(kps[f], okps[f]) for f in ("x", "y", "angle", "response", "octave"))):
-            bad += 1; print("ORB MISMATCH", w, h, x0, y0, len(kps), len(okps), flush=True)
-        n_orb += 1
-        nq, nt = int(rng.integers(0, 300)), int(rng.integers(0, 300))
-        q = rng.integers(0, 256, (nq, 32), dtype=np.uint8); t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
-        if nq and nt >= 2 and rng.integers(0, 2):
-            t[rng.integers(0, nt)] = t[0]; q[0] = t[0]
-        ratio = float(rng.choice([0.5, 0.7, 0.9, 1.0]))
-        if not np.array_equal(ctx.match_knn2_ratio(q, t, ratio), O.match_knn2_ratio(q, t, ratio)):
-            bad += 1; print("MATCH MISMATCH", nq, nt, ratio, flush=True)
-        n_m += 1
-        P = int(rng.integers(5, 300)); outl = float(rng.choice([0.0, 0.1, 0.3]))
-        sc = synth.gen_scene(P, int(rng.integers(0, 2**31)), outlier_frac=outl)
-        ok, mask, E, ni = ctx.find_essential_ransac(sc["p1"], sc["p2"], sc["K"])
-        r, omask, oE, st = O.find_essential_ransac(sc["p1"], sc["p2"], sc["K"])
-        if not (ok == (r > 0) and np.array_equal(mask, omask)):
-            bad += 1; print("E MISMATCH", P, outl, flush=True)
-        elif ok:
-            g, R, tt, m2 = ctx.recover_pose(oE, sc["p1"], sc["p2"], sc["K"], omask)
-            og, oR, ot, om2 = O.recover_pose(oE, sc["p1"], sc["p2"], sc["K"], omask)
-            if not (g == og and np.array_equal(m2, om2) and np.abs(R - oR).max() < 1e-9 and np.abs(tt - ot).max() < 1e-9):
-                bad += 1; print("RECOVERPOSE MISMATCH", P, outl, g, og, flush=True)
-            K = sc["K"]
-            P1 = K @ np.hstack([np.eye(3), np.zeros((3, 1))]); P2 = K @ np.hstack([oR, ot.reshape(3, 1)])
-            X3 = ctx.triangulate(P1, P2, sc["p1"], sc["p2"])
-            oX3, _ = O.triangulate(P1, P2, sc["p1"], sc["p2"])
-            if not np.array_equal(X3, oX3):
-                bad += 1; print("TRIANGULATE MISMATCH", P, flush=True)
-        n_e += 1
-print(f"fuzz done: LK {n_lk} H {n_h} F {n_f} PnP {n_p} ORB {n_orb} match {n_m} E/recoverPose/triangulate {n_e} cases, mismatches {bad}, {time.time() - t0:.0f} s", flush=True)
-sys.exit(1 if bad else 0)
+                bad += 1; print("E MISMATCH", P, outl, flush=True)
+            elif ok:
+                g, R, tt, m2 = ctx.recover_pose(oE, sc["p1"], sc["p2"], sc["K"], omask)
+                og, oR, ot, om2 = O.recover_pose(oE, sc["p1"], sc["p2"], sc["K"], omask)
+                if not (g == og and np.array_equal(m2, om2) and np.abs(R - oR).max() < 1e-9 and np.abs(tt - ot).max() < 1e-9):
+                    bad += 1; print("RECOVERPOSE MISMATCH", P, outl, g, og, flush=True)
+                K = sc["K"]
+                P1 = K @ np.hstack([np.eye(3), np.zeros((3, 1))]); P2 = K @ np.hstack([oR, ot.reshape(3, 1)])
+                X3 = ctx.triangulate(P1, P2, sc["p1"], sc["p2"])
+                oX3, _ = O.triangulate(P1, P2, sc["p1"], sc["p2"])
+                if not np.array_equal(X3, oX3):
+                    bad += 1; print("TRIANGULATE MISMATCH", P, flush=True)
+            n_e += 1
+    counts = dict(LK=n_lk, H=n_h, F=n_f, PnP=n_p, ORB=n_orb, match=n_m, E=n_e)
+    if verbose:
+        print(f"fuzz done: LK {n_lk} H {n_h} F {n_f} PnP {n_p} ORB {n_orb} match {n_m} E/recoverPose/triangulate {n_e} cases, mismatches {bad}, "
+              f"{time.time() - t0:.0f} s", flush=True)
+    return counts, bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 1)[1] else 0)

@@ -363,3 +363,69 @@ def test_resize_exact_follows_the_pixel_centre_mapping_at_orb_scales():
         ramp = np.tile(np.round(np.arange(sw) * 250.0 / (sw - 1)).astype(np.uint8), (sh, 1))
         gr = O.resize_linear_exact(ramp, dw, dh).astype(np.float64)
         assert np.abs(gr - (fx / (sw - 1) * 250.0)[None, :]).max() <= 1.01
+
+
+def _rot(rng, max_deg):
+    ax = rng.normal(size=3)
+    ax /= np.linalg.norm(ax)
+    return O.rodrigues(ax * np.deg2rad(rng.uniform(0, max_deg)))
+
+
+def test_epnp_recovers_planted_poses_on_exact_data():
+    """EPnP (epnp.cpp; the solvePnPRansac minimal kernel) from first principles: exact projections of random non-planar
+    points under a planted pose - 5 points (the RANSAC sample size), 6, 12 and 60 - must give the pose back.  The inputs are
+    rounded to float32 as OpenCV's are, hence the 1e-4 tolerance on well-conditioned configurations.  Long focal lengths
+    (a nearly orthographic camera, where more than one null vector of M^T M matters: the N = 2..4 branches of find_betas)
+    are included; they are only required to reproject the points."""
+    rng = np.random.default_rng(21)
+    worst_R = worst_t = worst_px = 0.0
+    for trial in range(60):
+        n = (5, 6, 12, 60)[trial % 4]
+        f = (400.0, 800.0, 5000.0)[trial % 3]
+        K = np.array([[f, 0, 320.0], [0, f, 240.0], [0, 0, 1]])
+        R = _rot(rng, 40)
+        t = np.array([rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), rng.uniform(4, 8)])
+        X = rng.uniform(-1.5, 1.5, (n, 3))
+        Xc = X @ R.T + t
+        uv = Xc[:, :2] / Xc[:, 2:] * f + np.array([320.0, 240.0])
+        r, tt = O.epnp(X.astype(np.float32), uv.astype(np.float32), K)
+        Rr = O.rodrigues(r)
+        Xc2 = X.astype(np.float32).astype(np.float64) @ Rr.T + tt
+        px = np.abs(Xc2[:, :2] / Xc2[:, 2:] * f + np.array([320.0, 240.0]) - uv).max()
+        worst_px = max(worst_px, px)
+        assert px < 0.05, (trial, n, f, px)                       # every configuration: the points reproject
+        if f < 1000 and n >= 6:                                   # well-conditioned: the pose itself comes back
+            worst_R = max(worst_R, np.abs(Rr - R).max())
+            worst_t = max(worst_t, np.abs(tt - t).max())
+    assert worst_R < 2e-4 and worst_t < 2e-3, (worst_R, worst_t, worst_px)
+
+
+def test_five_point_roots_satisfy_the_essential_constraints_and_hold_the_planted_motion():
+    """The 5-point solver (five-point.cpp, Nister) from first principles: on exact normalised correspondences of a planted
+    motion every returned matrix must be an essential matrix of the five points - x2^T E x1 = 0 for all five, det E = 0,
+    2 E E^T E - tr(E E^T) E = 0 - and the planted E = [t]x R must be among the roots (up to scale and sign)."""
+    rng = np.random.default_rng(22)
+    found = 0
+    for trial in range(40):
+        R = _rot(rng, 25)
+        t = rng.normal(size=3)
+        t /= np.linalg.norm(t)
+        X = np.c_[rng.uniform(-2, 2, (5, 2)), rng.uniform(4, 9, 5)]
+        x1 = X[:, :2] / X[:, 2:]
+        Xc = X @ R.T + t
+        x2 = Xc[:, :2] / Xc[:, 2:]
+        Es = O.e5_kernel(x1, x2)
+        assert 1 <= len(Es) <= 10
+        tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+        Egt = tx @ R
+        Egt /= np.linalg.norm(Egt)
+        h1, h2 = np.c_[x1, np.ones(5)], np.c_[x2, np.ones(5)]
+        best = 1e9
+        for E in Es:
+            En = E / np.linalg.norm(E)
+            assert np.abs(np.einsum("ni,ij,nj->n", h2, En, h1)).max() < 1e-8          # epipolar constraint on the sample
+            assert abs(np.linalg.det(En)) < 1e-8
+            assert np.abs(2 * En @ En.T @ En - np.trace(En @ En.T) * En).max() < 1e-7  # two equal singular values, one zero
+            best = min(best, np.abs(En - Egt).max(), np.abs(En + Egt).max())
+        found += best < 1e-6
+    assert found == 40
