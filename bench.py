@@ -74,6 +74,7 @@ def parse_args():
     ap.add_argument("--max-points", type=int, default=None, help="track capacity per stream (default 4096; 8192 above 2000 features)")
     ap.add_argument("--ingest-steps", type=int, default=16, help="steps of the value_with_ingest phase (0 = skip)")
     ap.add_argument("--ingest-ring", type=int, default=3, help="ring entries the ingest phase cycles through (uploads run ring - 1 frames ahead)")
+    ap.add_argument("--compute-streams", type=int, default=0, help="HIP streams the contexts' steps are enqueued on (context c uses stream c %% N; 0 = every context its own)")
     ap.add_argument("--depth", type=int, default=1, help="steps kept in flight per context (1 or 2: mvo_batch_track_async pipelines two)")
     ap.add_argument("--extra-steps", type=int, default=5, help="steps of the always-on and key-frame-every-frame phases (0 = skip)")
     ap.add_argument("--single-steps", type=int, default=30, help="steps of the single-stream measurement (0 = skip)")
@@ -388,10 +389,12 @@ def main():
 
     # ---- contexts: frames resident in the device ring, seeded with depth landmarks -------------------------------------
     ctxs = []
-    mk = lambda: Context(max_width=W, max_height=H, batch=B, nfeatures=args.nfeatures, max_points=maxpts, ring_frames=n_frames, device=local_rank)
-    pre = [mk() for _ in range(C)] if args.contexts_first else None     # diagnostic: creation order must not matter
+    shared = [torch.cuda.Stream(device=dev) for _ in range(args.compute_streams)]       # kept alive for the run
+    mk = lambda c: Context(max_width=W, max_height=H, batch=B, nfeatures=args.nfeatures, max_points=maxpts, ring_frames=n_frames, device=local_rank,
+                           **({"hip_stream": shared[c % len(shared)].cuda_stream} if shared else {}))
+    pre = [mk(c) for c in range(C)] if args.contexts_first else None     # diagnostic: creation order must not matter
     for c in range(C):
-        ctx = pre[c] if pre else mk()
+        ctx = pre[c] if pre else mk(c)
         ctx.batch_set_intrinsics(Kmat, dcoef)
         for f in range(n_frames):
             ctx.batch_upload_async(f, frames[c, f].data_ptr(), W, H, pitch, H * pitch)     # device -> device, one copy per frame
