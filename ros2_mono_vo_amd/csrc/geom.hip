@@ -21,6 +21,7 @@
 // the winning model by all lanes.  No MFMA: nothing here is a dense contraction.
 #include "mvo_internal.h"
 #include "geom_models.h"
+#include "track_policy.h"
 
 #include <cstdlib>
 
@@ -522,6 +523,7 @@ struct PnpRefineArgs {
   const int* n;         // [B] correspondences per slot
   double* pose;      // [B][8]
   CamK cam;
+  TrkKeyframePolicy kp;   // kp.state == null: none
 };
 
 // ---- wave-cooperative one-sided Jacobi SVD ------------------------------------------------------------------------------
@@ -616,7 +618,7 @@ __device__ __forceinline__ void wave_jacobi_svd(double* At, double* W, double* V
 // accumulators of a pass over the points are at most 28 doubles per thread (the DLT normal matrix takes three passes): no
 // scratch, <= 128 VGPRs, so four of these wavefronts share a SIMD with anything.
 template <int PR_T>
-__global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRefineArgs A) {
+__device__ __forceinline__ void pnp_refine_slot(const PnpRefineArgs& A) {
   constexpr int PR_NW = PR_T / 64;
   __shared__ double s_red[PR_NW * 28];
   __shared__ double s_sh[64];       // broadcast area: Vt of the planarity test / the pose / dR/dr of an evaluation
@@ -1021,6 +1023,13 @@ __global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRe
 #endif
 }
 
+template <int PR_T>
+__global__ __launch_bounds__(PR_T, PR_WAVES_PER_EU) void pnp_refine_kernel(PnpRefineArgs A) {
+  pnp_refine_slot<PR_T>(A);
+  // the tracker's per-slot decision after PnP, by the thread that wrote this slot's pose and status
+  if (A.kp.state && threadIdx.x == 0) trk_policy_keyframe_slot(A.kp, blockIdx.x, A.result + (size_t)blockIdx.x * 8, A.pose + (size_t)blockIdx.x * 8);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // triangulation (one point per lane) and recoverPose
 // ---------------------------------------------------------------------------------------------------
@@ -1172,7 +1181,7 @@ int geom_ransac_f(mvo_ctx* ctx, int nslots, const float* p1, const float* p2, co
   return MVO_OK;
 }
 int geom_pnp(mvo_ctx* ctx, int nslots, const float* obj, const float* img, const int* d_n, const double K[9], const double* dist5, int iters,
-             float reproj, double conf, u8* mask, double* model, int* result, int* inl, double* pose, hipStream_t st) {
+             float reproj, double conf, u8* mask, double* model, int* result, int* inl, double* pose, hipStream_t st, const TrkKeyframePolicy* kp) {
   if (!st) st = ctx->stream;
   ModelParams P{};
   P.cam = make_camk(K, dist5);
@@ -1184,6 +1193,7 @@ int geom_pnp(mvo_ctx* ctx, int nslots, const float* obj, const float* img, const
   ProfScope ps2(ctx, "pnp_refine", st);
   PnpRefineArgs R;
   R.obj = obj; R.img = img; R.stride_pts = ctx->maxpts; R.inl = inl; R.result = result; R.model = model; R.n = d_n; R.pose = pose; R.cam = P.cam;
+  if (kp) R.kp = *kp; else memset(&R.kp, 0, sizeof(R.kp));
   const bool wide = ctx->refine_waves ? ctx->refine_waves == 4 : nslots <= 64;
   if (wide) hipLaunchKernelGGL(pnp_refine_kernel<256>, dim3(nslots), dim3(256), 0, st, R);
   else hipLaunchKernelGGL(pnp_refine_kernel<64>, dim3(nslots), dim3(64), 0, st, R);

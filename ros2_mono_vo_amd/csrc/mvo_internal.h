@@ -241,7 +241,9 @@ int trk_ring_events(mvo_ctx* ctx);                  // upload stream + ring even
 int trk_wait_upload(mvo_ctx* ctx, int frame_idx);   // ctx->stream waits for an asynchronous upload into ring entry frame_idx
 int trk_output_seed(mvo_ctx* ctx, int slot, const float* d_lm, int n);   // output side: the seed landmarks open the slot's map
 int trk_sync_upload(mvo_ctx* ctx);                  // host waits for the upload stream
-void lk_filter_compact_launch(mvo_ctx* ctx, hipStream_t st);   // pipeline.hip: status/err filter of all slots
+struct TrkLostPolicy;
+struct TrkKeyframePolicy;
+void lk_filter_compact_launch(mvo_ctx* ctx, hipStream_t st, const TrkLostPolicy* lost = nullptr);   // pipeline.hip: status/err filter of all slots (+ the LOST policy)
 
 // device-level stage drivers (all slots per launch)
 int lk_build_pyramid(mvo_ctx* ctx, int set, const LkLevels& L, int nslots, hipStream_t st = nullptr, const u8* l0 = nullptr,
@@ -270,7 +272,8 @@ int geom_ransac_h(mvo_ctx* ctx, int nslots, const float* p1, const float* p2, co
 int geom_ransac_f(mvo_ctx* ctx, int nslots, const float* p1, const float* p2, const int* d_n, double thr, int max_iters, double conf,
                   u8* mask, double* model, int* result, hipStream_t st, int* work_ctr = nullptr, int grid = 0);
 int geom_pnp(mvo_ctx* ctx, int nslots, const float* obj, const float* img, const int* d_n, const double K[9], const double* dist5, int iters,
-             float reproj, double conf, u8* mask, double* model, int* result, int* inl, double* pose, hipStream_t st);
+             float reproj, double conf, u8* mask, double* model, int* result, int* inl, double* pose, hipStream_t st,
+             const TrkKeyframePolicy* kp = nullptr);   // kp: the key-frame policy of the tracker step at the end of each slot's refine
 int geom_triangulate_matches(mvo_ctx* ctx, int nslots, int max_matches, const mvo_match* matches, const int* n_matches,
                              const float* kf_xy, const float* cur_xy, const double* kf_pose, const double* cur_pose,
                              const int* pnp_result, const double K[9], float* X3, u8* valid, const int* d_list = nullptr,

@@ -3,6 +3,7 @@
 // landmarks), the track accessors, and the HIP-event stage timers.  The per-frame step itself is csrc/track.hip.
 // All per-stream state (previous pyramid, tracked points, landmarks, key-frame descriptors) stays in HBM.
 #include "mvo_internal.h"
+#include "track_policy.h"
 
 #include <dlfcn.h>
 
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(LKF_T) void lk_filter_compact_kernel(const float* _
                                                                  const float* __restrict__ lm, const float* __restrict__ kf,
                                                                  float thresh, int maxpts, float* __restrict__ o_pts,
                                                                  float* __restrict__ o_lm, float* __restrict__ o_kf,
-                                                                 int* __restrict__ o_n) {
+                                                                 int* __restrict__ o_n, TrkLostPolicy lost) {
   __shared__ int s_wave[LKF_T / 64];
   __shared__ int s_base;
   const int slot = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -219,13 +220,17 @@ __global__ __launch_bounds__(LKF_T) void lk_filter_compact_kernel(const float* _
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) o_n[slot] = s_base;
+  if (threadIdx.x == 0) {
+    o_n[slot] = s_base;
+    if (lost.state) trk_policy_lost_slot(lost, slot, s_base);
+  }
 }
 
-void lk_filter_compact_launch(mvo_ctx* ctx, hipStream_t st) {
+void lk_filter_compact_launch(mvo_ctx* ctx, hipStream_t st, const TrkLostPolicy* lost) {
   PipeState* p = ctx->pipe;
   hipLaunchKernelGGL(lk_filter_compact_kernel, dim3(ctx->B), dim3(LKF_T), 0, st, ctx->d_next_pts, ctx->d_status, ctx->d_err, ctx->d_npts,
-                     p->d_lm, p->d_kf_pts, ctx->cfg.tracking_error_thresh, ctx->maxpts, p->d_cur_pts, p->d_cur_lm, p->d_cur_kf, p->d_ncur);
+                     p->d_lm, p->d_kf_pts, ctx->cfg.tracking_error_thresh, ctx->maxpts, p->d_cur_pts, p->d_cur_lm, p->d_cur_kf, p->d_ncur,
+                     lost ? *lost : TrkLostPolicy{nullptr, 0, nullptr, nullptr, nullptr});
 }
 
 // dense ORB output (all slots back to back) -> per-slot matcher / track layout

@@ -18,6 +18,7 @@
 // Ingest is asynchronous as well: mvo_batch_upload_async copies pinned host frames into the device ring on a dedicated
 // stream while the previous step computes.
 #include "mvo_internal.h"
+#include "track_policy.h"
 
 #include <cfloat>
 #include <cmath>
@@ -35,7 +36,7 @@ struct TrackState {
   int* d_pt_base = nullptr;    // [B+1] LK work list: first item of each slot
   int* d_work_slot = nullptr;  // [B*maxpts] LK work list: slot of each item
   int* d_work_ctr = nullptr;   // [8] claim counters of the LK work list, one per XCD part
-  int* d_hf_ctr = nullptr;     // [2] slot-queue counters of the H and the F launch (zeroed by trk_policy_keyframe_kernel)
+  int* d_hf_ctr = nullptr;     // [2] slot-queue counters of the H and the F launch (zeroed by slot 0's refine workgroup, trk_policy_keyframe_slot)
   bool res_valid = false;      // h_res holds the results of the step collected last (host-side forecast of the key-frame tests)
   int* d_err = nullptr;        // [1] capacity flags raised on the device
   u8* d_mask_f = nullptr;      // [B][maxpts] F consensus mask (H uses geom->d_mask2)
@@ -132,92 +133,6 @@ __global__ __launch_bounds__(256) void trk_worklist_expand_kernel(const int* __r
   const int s = blockIdx.x;
   const int b = pt_base[s], e = pt_base[s + 1];
   for (int i = b + threadIdx.x; i < e; i += 256) work_slot[i] = s;
-}
-
-// After the status/err filter: min_tracked_points -> LOST (src/tracker.cpp:292-296); the others go on to PnP.
-__global__ __launch_bounds__(256) void trk_policy_lost_kernel(int* __restrict__ state, const int* __restrict__ ncur, int B,
-                                                              long long min_tracked, int* __restrict__ n_pnp, int* __restrict__ flags,
-                                                              mvo_step_result* __restrict__ res) {
-  const int s = blockIdx.x * 256 + threadIdx.x;
-  if (s >= B) return;
-  int n = 0;
-  if (state[s] == MVO_TRACK_TRACKING) {
-    const int nc = ncur[s];
-    res[s].n_tracked = nc;
-    if ((long long)nc < min_tracked) { state[s] = MVO_TRACK_LOST; flags[s] |= MVO_STEP_LOST_NOW; }
-    else n = nc;
-  }
-  n_pnp[s] = n;
-}
-
-__device__ inline void trk_rodrigues(const double r_[3], double R[9]) {   // calibration.cpp cvRodrigues2, vector -> matrix
-  double rx = r_[0], ry = r_[1], rz = r_[2];
-  const double theta = sqrt(rx * rx + ry * ry + rz * rz);
-  if (theta < DBL_EPSILON) {
-    for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1 : 0;
-    return;
-  }
-  const double c = cos(theta), s = sin(theta), c1 = 1. - c, it = 1. / theta;
-  rx *= it; ry *= it; rz *= it;
-  const double rrt[9] = {rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz};
-  const double r_x[9] = {0, -rz, ry, rz, 0, -rx, -ry, rx, 0};
-  for (int k = 0; k < 9; k++) R[k] = c * ((k % 4 == 0) ? 1. : 0.) + c1 * rrt[k] + s * r_x[k];
-}
-
-// After PnP: pose, ++tracking_count_from_keyframe_, should_add_keyframe (src/tracker.cpp:318-319, 118-136, 92-116).
-// The reference does not look at solvePnPRansac's return value; without a model its pose for the frame is whatever an
-// uninitialised 3x1 Mat holds (include/mvo.h, MVO_STEP_PNP_FAILED).  Defined here: no pose for the frame, the count still
-// advances, no key-frame test, the stream keeps tracking (trk_finalize_kernel carries the LK survivors forward).
-__global__ __launch_bounds__(256) void trk_policy_keyframe_kernel(int* __restrict__ state, int* __restrict__ count, int B,
-                                                                  const int* __restrict__ n_pnp, const int* __restrict__ pnp_result,
-                                                                  const double* __restrict__ pose, const double* __restrict__ kf_pose,
-                                                                  long long min_obs, long long max_after, double max_trans,
-                                                                  double max_rot, int policy, int* __restrict__ n_hf,
-                                                                  int* __restrict__ flags, mvo_step_result* __restrict__ res,
-                                                                  int* __restrict__ hf_ctr) {
-  const int s = blockIdx.x * 256 + threadIdx.x;
-  if (s < 2) hf_ctr[s] = 0;   // slot queues of the H and F launches that follow
-  if (s >= B) return;
-  int nhf = 0;
-  const int n = n_pnp[s];
-  if (n > 0 && state[s] == MVO_TRACK_TRACKING) {
-    const int ok = pnp_result[8 * s] && pnp_result[8 * s + 6];
-    res[s].pnp_ok = ok;
-    res[s].n_pnp_inliers = pnp_result[8 * s + 5];
-    if (!ok) {
-      flags[s] |= MVO_STEP_PNP_FAILED;
-      count[s] = count[s] + 1;
-    } else {
-      const double* p = pose + 8 * s;
-      for (int k = 0; k < 3; k++) { res[s].rvec[k] = p[k]; res[s].tvec[k] = p[3 + k]; }
-      flags[s] |= MVO_STEP_POSE;
-      const int c = count[s] + 1;
-      count[s] = c;
-      bool add = (long long)n < min_obs || (long long)c > max_after;
-      if (!add) {
-        // has_significant_motion: relative pose kf_wc^-1 * cur_wc = T_kf_cw * T_cur_cw^-1
-        double Rk[9], Rc[9];
-        trk_rodrigues(kf_pose + 8 * s, Rk);
-        trk_rodrigues(p, Rc);
-        const double* tk = kf_pose + 8 * s + 3;
-        double Rr[9];
-        for (int i = 0; i < 3; i++)
-          for (int j = 0; j < 3; j++) Rr[3 * i + j] = Rk[3 * i] * Rc[3 * j] + Rk[3 * i + 1] * Rc[3 * j + 1] + Rk[3 * i + 2] * Rc[3 * j + 2];
-        double tr[3];
-        for (int i = 0; i < 3; i++) tr[i] = tk[i] - (Rr[3 * i] * p[3] + Rr[3 * i + 1] * p[4] + Rr[3 * i + 2] * p[5]);
-        const double translation = sqrt(tr[0] * tr[0] + tr[1] * tr[1] + tr[2] * tr[2]);
-        if (translation > max_trans) add = true;
-        else {
-          const double rotation = acos((Rr[0] + Rr[4] + Rr[8] - 1.0) / 2.0);   // NaN outside [-1, 1]: the test below is false
-          add = rotation > max_rot;
-        }
-      }
-      if (policy == 1) add = true;
-      if (policy == 2) add = false;
-      if (add) { nhf = n; flags[s] |= MVO_STEP_KF_CHECKED; }
-    }
-  }
-  n_hf[s] = nhf;
 }
 
 // After H / F: has_parallax (src/tracker.cpp:253-265, divisions unguarded as there) and the ordered list of the slots
@@ -766,19 +681,21 @@ static int trk_step_enqueue(mvo_ctx* ctx, int frame_idx) {
   p->rd_pending[prev_entry] = 1;
   {
     ProfScope ps(ctx, "lk_filter");
-    lk_filter_compact_launch(ctx, st);
-    hipLaunchKernelGGL(trk_policy_lost_kernel, dim3(nb), dim3(256), 0, st, t->d_state, p->d_ncur, B, (long long)c.min_tracked_points,
-                       t->d_n_pnp, t->d_flags, t->d_res);
+    // + min_tracked_points -> LOST (src/tracker.cpp:292-296) at the end of each slot's workgroup
+    const TrkLostPolicy lp{t->d_state, (long long)c.min_tracked_points, t->d_n_pnp, t->d_flags, t->d_res};
+    lk_filter_compact_launch(ctx, st, &lp);
   }
   // ---- PnP on the slots that still track ----------------------------------------------------------------------------------
   {
+    // + pose, ++tracking_count_from_keyframe_, should_add_keyframe (src/tracker.cpp:318-319) at the end of each slot's refine
+    // workgroup: a separate 5 us kernel for it took 0.3-0.7 ms of stream time beside three other contexts (step anatomy)
     ProfScope ps(ctx, "pnp");
+    const TrkKeyframePolicy kp{t->d_state, t->d_count, t->d_n_pnp, p->d_kf_pose, (long long)c.min_observations_before_triangulation,
+                               (long long)c.max_tracking_after_keyframe, c.max_translation_from_keyframe, c.max_rotation_from_keyframe, t->policy,
+                               t->d_n_hf, t->d_flags, t->d_res, t->d_hf_ctr};
     geom_pnp(ctx, B, p->d_cur_lm, p->d_cur_pts, t->d_n_pnp, p->K, p->dist, 100, 8.0f, 0.99, g->d_mask, g->d_model, g->d_result, g->d_inl,
-             g->d_pose, st);
+             g->d_pose, st, &kp);
   }
-  hipLaunchKernelGGL(trk_policy_keyframe_kernel, dim3(nb), dim3(256), 0, st, t->d_state, t->d_count, B, t->d_n_pnp, g->d_result, g->d_pose,
-                     p->d_kf_pose, (long long)c.min_observations_before_triangulation, (long long)c.max_tracking_after_keyframe,
-                     c.max_translation_from_keyframe, c.max_rotation_from_keyframe, t->policy, t->d_n_hf, t->d_flags, t->d_res, t->d_hf_ctr);
   // ---- has_parallax on the slots whose key-frame test fired -----------------------------------------------------------
   // Persistent workgroups over a slot queue, as many as the host FORECASTS tests from the results of the step collected last
   // (should_add_keyframe's count / observation rules are known one frame ahead; the motion rule is not: a slot the
