@@ -287,7 +287,7 @@ struct LkArgs {
   double eps2;
   double min_eig;
   // device-driven launch (frame-batch tracker): the points of all slots form one dense work list,
-  // work_slot[w] = slot of item w, pt_base[slot] = first item of the slot, pt_base[nslots] = item count; persistent
+  // work_slot[w] = slot << 16 | point of item w, pt_base[slot] = first item of the slot, pt_base[nslots] = item count; persistent
   // wavefronts claim four items at a time (one per DPP row) from the eight counters work_ctr[0..8) (one per XCD part of the
   // list, zeroed before the launch).  Null: points blockIdx.x * 4 .. + 3 of slot blockIdx.y with the host-sized grid.
   const int* work_slot;
@@ -765,9 +765,10 @@ __global__ __launch_bounds__(64, LK_WAVES_PER_EU) void lk_track_kernel(LkArgs A)
         if (w0 >= hi) break;
         const int w = w0 + g;
         bool valid = w < hi;
-        const int slot = valid ? min(max(A.work_slot[w], 0), A.nslots - 1) : 0;
-        const int p = w - A.pt_base[slot];
-        valid = valid && p >= 0 && p < A.maxpts;   // always true for a consistent list
+        const int item = valid ? A.work_slot[w] : 0;   // slot << 16 | point (the slot's items in an order of the caller's choice)
+        const int slot = min(max(item >> 16, 0), A.nslots - 1);
+        const int p = item & 0xFFFF;
+        valid = valid && p < A.maxpts;   // always true for a consistent list
         lk_track_group(A, S, slot, p, valid, l);
       }
     }

@@ -95,6 +95,7 @@ int upload_gray(mvo_ctx* ctx, const uint8_t* img, int w, int h, int stride, int 
 static int mvo_create_impl(const mvo_config* cfg, mvo_ctx** out) {
   if (!cfg || !out) return MVO_E_ARG;
   if (cfg->max_width < 32 || cfg->max_height < 32 || cfg->batch < 1 || cfg->max_points < 16) return MVO_E_ARG;
+  if (cfg->ring_frames > 0 && (cfg->max_points > 65535 || cfg->batch > 32767)) return MVO_E_ARG;   // the LK work list packs slot << 16 | point
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return MVO_E_HIP;  // fail loudly: no CPU fallback
   mvo_ctx* ctx = new mvo_ctx();
