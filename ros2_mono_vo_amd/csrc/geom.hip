@@ -288,6 +288,24 @@ __device__ __forceinline__ void ransac_slot(const RansacArgs& A, const int slot)
     // ---- 3. minimal solver, one hypothesis per lane; only as many as can still be consumed ---------------
     const int nsolve = min(npass, want);
     int nm = 0;
+    if constexpr (M::LANES > 1) {
+      // M::LANES adjacent lanes per hypothesis (EPnP: one beta approximation each); hypothesis h on lanes LANES h ..
+      static_assert(NW == 1 && !M::WIDE && M::WS > 0 && M::CH * M::LANES <= 64, "cooperative solves are a single-wave mode");
+      const int hyp = lane / M::LANES, sub = lane - hyp * M::LANES;
+      if (hyp < ch && hyp < nsolve) {
+        for (int i = 0; i < M::MP; i++) {
+          int id = s_idx[hyp][i];
+          for (int k = 0; k < M::PT1; k++) ms1[i * M::PT1 + k] = m1[(size_t)id * M::PT1 + k];
+          for (int k = 0; k < M::PT2; k++) ms2[i * M::PT2 + k] = m2[(size_t)id * M::PT2 + k];
+        }
+        double models[M::MAXM * M::MS];
+        nm = M::solve_coop(A.P, ms1, ms2, models, s_ws + hyp * WSS, sub);
+        if (sub == 0) {
+          s_nmodels[hyp] = nm;
+          for (int k = 0; k < M::MS; k++) s_models[hyp][0][k] = models[k];
+        }
+      }
+    } else
     if (cand >= 0 && cand < nsolve) {
       for (int i = 0; i < M::MP; i++) {
         int id = s_idx[cand][i];

@@ -45,6 +45,7 @@ struct ModelParams { CamK cam; };
 #define RS_H_OVERDRAW 1
 #endif
 struct HModel {
+  static constexpr int LANES = 1;
   static constexpr bool SEQ_SCORE = false;   // score all hypotheses of a round, then replay (geom.hip)
   static constexpr int MP = 4, MAXM = 1, MS = 9, PT1 = 2, PT2 = 2;
   // 16 hypotheses per round, every round in LDS (16 x 193 doubles = 25 KB): a 64-wide round with 48 workspaces in
@@ -160,6 +161,7 @@ struct HModel {
 // Fundamental matrix, 7 points (FMEstimatorCallback / run7Point)
 // ---------------------------------------------------------------------------------------------------
 struct FModel {
+  static constexpr int LANES = 1;
   static constexpr bool SEQ_SCORE = false;   // score all hypotheses of a round, then replay (geom.hip)
   static constexpr int MP = 7, MAXM = 3, MS = 9, PT1 = 2, PT2 = 2;
   static constexpr int CH = 16, WS = 63 + 81 + 81 + 49;  // a, v, ta, tv
@@ -953,14 +955,28 @@ __device__ GL_NOINLINE double ep_compute_R_and_t(EpnpState& e, const double* ut,
 // solvePnP(SOLVEPNP_EPNP) for 5 float correspondences -> rvec, tvec
 // ws: 288 doubles.  [0,144) MtM, rotated in place into Ut by the SVD; [144,276) first M (2n x 12 = 120), then dv (72) + L (60) and,
 // over the dead dv, the workspaces of the three small least-squares solves; [276,288) singular values.
+// sub < 0: one lane does everything.  sub = 0, 1, 2: THREE ADJACENT LANES of a wavefront solve one problem together (all three
+// call with the same inputs and the same LDS workspace): the 12 x 12 SVD - half of the 0.74 ms of a solve, pinned to its
+// sequential pair and summation order by bit-exactness - stays on lane 0, but the three beta approximations with their
+// Gauss-Newton and R, t estimation (46 %) are independent given Ut and L and run one per lane, each the same instruction
+// sequence as in the one-lane form, with workspaces in the dead parts of the hypothesis's LDS block (dv, rows 0..7 of Ut).
+// The winner is chosen in the one-lane order; lane 0 returns it.  Results are bit-identical to the one-lane form.
 #ifdef EP_TIMING
 __device__ long long g_ep_ticks[8];
 #define EP_TICK(k) { long long tn_ = wall_clock64(); if (threadIdx.x == 0 && blockIdx.x == 0) g_ep_ticks[k] += tn_ - tq_; tq_ = tn_; }
 #else
 #define EP_TICK(k)
 #endif
-__device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const CamK& cam, double rvec[3], double tvec[3], double* ws) {
+__device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const CamK& cam, double rvec[3], double tvec[3], double* ws, const int sub = -1) {
   const int n = EP_N;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const bool coop = sub >= 0;
+#define EP_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#else
+  const bool coop = false;   // the host checks of this header run the one-lane form
+  (void)sub;
+#define EP_FENCE() do {} while (0)
+#endif
 #ifdef EP_TIMING
   long long tq_ = wall_clock64();
 #endif
@@ -1014,7 +1030,7 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
   // M (2n x 12), MtM, SVD
   double* ut = ws;
   double* ws2 = ws + 144;
-  {
+  if (!coop || sub == 0) {
     double* M = ws2;
     for (int i = 0; i < n; i++) {
       const double* as = &e.alphas[4 * i];
@@ -1048,7 +1064,8 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
   double* dvm = ws2;         // [4][6][3], dead once L is built
   double* l_6x10 = ws2 + 72; // [6][10]; the small solves below use ws2[0, 61)
   double rho[6];
-  {
+  if (coop) EP_FENCE();
+  if (!coop || sub == 0) {
 #pragma unroll 1
     for (int i = 0; i < 4; i++) {
       const double* vi = ut + 12 * (11 - i);
@@ -1078,52 +1095,68 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
       row[8] = 2.0f * ep_dot(d2, d3);
       row[9] = ep_dot(d3, d3);
     }
+  }
+  if (coop) EP_FENCE();
+  {
     rho[0] = ep_dist2(e.cws[0], e.cws[1]); rho[1] = ep_dist2(e.cws[0], e.cws[2]); rho[2] = ep_dist2(e.cws[0], e.cws[3]);
     rho[3] = ep_dist2(e.cws[1], e.cws[2]); rho[4] = ep_dist2(e.cws[1], e.cws[3]); rho[5] = ep_dist2(e.cws[2], e.cws[3]);
   }
   EP_TICK(2)
   double Betas[4][4], rep_errors[4] = {0, 0, 0, 0};
   double Rs[4][3][3], ts[4][3];
-  {  // find_betas_approx_1
-    double l[24], b4[4];
-    for (int i = 0; i < 6; i++) { l[i * 4] = l_6x10[i * 10]; l[i * 4 + 1] = l_6x10[i * 10 + 1]; l[i * 4 + 2] = l_6x10[i * 10 + 3]; l[i * 4 + 3] = l_6x10[i * 10 + 6]; }
-    gl_solve_svd_ws(l, 6, 4, rho, b4, ws2, ws2 + 36);
-    double* betas = Betas[1];
-    if (b4[0] < 0) { betas[0] = sqrt(-b4[0]); betas[1] = -b4[1] / betas[0]; betas[2] = -b4[2] / betas[0]; betas[3] = -b4[3] / betas[0]; }
-    else { betas[0] = sqrt(b4[0]); betas[1] = b4[1] / betas[0]; betas[2] = b4[2] / betas[0]; betas[3] = b4[3] / betas[0]; }
-  }
-  EP_TICK(3)
-  ep_gauss_newton(l_6x10, rho, Betas[1]);
-  EP_TICK(4)
-  rep_errors[1] = ep_compute_R_and_t(e, ut, Betas[1], Rs[1], ts[1]);
-  EP_TICK(5)
-  {  // find_betas_approx_2
-    double l[18], b3[3];
-    for (int i = 0; i < 6; i++) { l[i * 3] = l_6x10[i * 10]; l[i * 3 + 1] = l_6x10[i * 10 + 1]; l[i * 3 + 2] = l_6x10[i * 10 + 2]; }
-    gl_solve_svd_ws(l, 6, 3, rho, b3, ws2, ws2 + 36);
-    double* betas = Betas[2];
-    if (b3[0] < 0) { betas[0] = sqrt(-b3[0]); betas[1] = (b3[2] < 0) ? sqrt(-b3[2]) : 0.0; }
-    else { betas[0] = sqrt(b3[0]); betas[1] = (b3[2] > 0) ? sqrt(b3[2]) : 0.0; }
-    if (b3[1] < 0) betas[0] = -betas[0];
-    betas[2] = 0.0; betas[3] = 0.0;
-  }
-  ep_gauss_newton(l_6x10, rho, Betas[2]);
-  rep_errors[2] = ep_compute_R_and_t(e, ut, Betas[2], Rs[2], ts[2]);
-  {  // find_betas_approx_3
-    double l[30], b5[5];
+  // workspaces of the three small solves: one after the other in ws2[0, 61) on one lane; side by side when three lanes share
+  // the problem: dv[0, 40), dv[40, 67) and rows 0..4 of Ut (dead: R, t only read rows 8..11)
+  // ONE instruction stream for the three approximations (lanes that share a problem must not diverge, or they take turns):
+  // approximation a solves the 6 x ncol[a] system of its columns of L, turns the solution into betas by its own rule, then
+  // Gauss-Newton and R, t - the same calls for all three.  One lane runs a = 0, 1, 2 in turn, three lanes one each.
+  for (int a = coop ? sub : 0; a < (coop ? sub + 1 : 3); a++) {
+    const int nc = a == 0 ? 4 : (a == 1 ? 3 : 5);
+    double* w = !coop ? ws2 : (a == 0 ? ws2 : (a == 1 ? ws2 + 40 : ut));
+    double l[30], bb[5] = {0, 0, 0, 0, 0};
     for (int i = 0; i < 6; i++)
-      for (int j = 0; j < 5; j++) l[i * 5 + j] = l_6x10[i * 10 + j];
-    gl_solve_svd_ws(l, 6, 5, rho, b5, ws2, ws2 + 36);
-    double* betas = Betas[3];
-    if (b5[0] < 0) { betas[0] = sqrt(-b5[0]); betas[1] = (b5[2] < 0) ? sqrt(-b5[2]) : 0.0; }
-    else { betas[0] = sqrt(b5[0]); betas[1] = (b5[2] > 0) ? sqrt(b5[2]) : 0.0; }
-    if (b5[1] < 0) betas[0] = -betas[0];
-    betas[2] = b5[3] / betas[0];
-    betas[3] = 0.0;
+      for (int j = 0; j < nc; j++) {
+        const int col = a == 0 ? (j == 2 ? 3 : (j == 3 ? 6 : j)) : j;   // approximation 1 takes columns 0, 1, 3, 6 of L
+        l[i * nc + j] = l_6x10[i * 10 + col];
+      }
+    gl_solve_svd_ws(l, 6, nc, rho, bb, w, w + 6 * nc);
+    double* betas = Betas[1 + a];
+    if (a == 0) {   // find_betas_approx_1
+      if (bb[0] < 0) { betas[0] = sqrt(-bb[0]); betas[1] = -bb[1] / betas[0]; betas[2] = -bb[2] / betas[0]; betas[3] = -bb[3] / betas[0]; }
+      else { betas[0] = sqrt(bb[0]); betas[1] = bb[1] / betas[0]; betas[2] = bb[2] / betas[0]; betas[3] = bb[3] / betas[0]; }
+    } else {        // find_betas_approx_2 / _3
+      if (bb[0] < 0) { betas[0] = sqrt(-bb[0]); betas[1] = (bb[2] < 0) ? sqrt(-bb[2]) : 0.0; }
+      else { betas[0] = sqrt(bb[0]); betas[1] = (bb[2] > 0) ? sqrt(bb[2]) : 0.0; }
+      if (bb[1] < 0) betas[0] = -betas[0];
+      betas[2] = a == 2 ? bb[3] / betas[0] : 0.0;
+      betas[3] = 0.0;
+    }
+    EP_TICK(3)
+    ep_gauss_newton(l_6x10, rho, betas);
+    EP_TICK(4)
+    rep_errors[1 + a] = ep_compute_R_and_t(e, ut, betas, Rs[1 + a], ts[1 + a]);
+    EP_TICK(5)
   }
-  ep_gauss_newton(l_6x10, rho, Betas[3]);
-  rep_errors[3] = ep_compute_R_and_t(e, ut, Betas[3], Rs[3], ts[3]);
   EP_TICK(6)
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (coop) {
+    // the three lanes' candidates side by side: errors to every lane, then the winner's R, t to lane 0 (one-lane order of the tests)
+    const int base = (int)(threadIdx.x & 63) - sub;
+    const double mine = rep_errors[1 + sub];
+    const double e1 = __shfl(mine, base, 64), e2 = __shfl(mine, base + 1, 64), e3 = __shfl(mine, base + 2, 64);
+    int Nc = 1;
+    if (e2 < e1) Nc = 2;
+    if (e3 < (Nc == 1 ? e1 : e2)) Nc = 3;
+    double R[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      tvec[i] = __shfl(ts[1 + sub][i], base + Nc - 1, 64);
+#pragma unroll
+      for (int j = 0; j < 3; j++) R[i * 3 + j] = __shfl(Rs[1 + sub][i][j], base + Nc - 1, 64);
+    }
+    if (sub == 0) gm_rodrigues_m2v(R, rvec);
+    return;
+  }
+#endif
   int N = 1;
   if (rep_errors[2] < rep_errors[1]) N = 2;
   if (rep_errors[3] < rep_errors[N]) N = 3;
@@ -1147,6 +1180,7 @@ __device__ GL_NOINLINE void gm_epnp5(const float* obj, const float* img, const C
 #endif
 struct PnPModel {
   static constexpr bool SEQ_SCORE = true;    // score + replay hypothesis by hypothesis: the loop usually ends after a few
+  static constexpr int LANES = 3;            // lanes per hypothesis in the solver (gm_epnp5: one beta approximation each)
   static constexpr int MP = 5, MAXM = 1, MS = 6, PT1 = 3, PT2 = 2;
   // Every round is 20 wide with the workspaces in LDS (20 x 289 doubles = 46 KB): a round is latency bound, ~0.85 ms
   // whatever its width, while a 64-wide round with 48 workspaces in private memory took 3.8 ms - more per hypothesis
@@ -1169,6 +1203,13 @@ struct PnPModel {
     double rvec[3], tvec[3];
     gm_epnp5(ms1, ms2, P.cam, rvec, tvec, ws);
     for (int i = 0; i < 3; i++) { model[2 * i] = rvec[i]; model[2 * i + 1] = tvec[i]; }  // hconcat(rvec, tvec)
+    return 1;
+  }
+  // the same by LANES adjacent lanes (lane `sub` of them): the model is valid on sub == 0
+  __device__ static int solve_coop(const ModelParams& P, const float* ms1, const float* ms2, double* model, double* ws, int sub) {
+    double rvec[3] = {0, 0, 0}, tvec[3] = {0, 0, 0};
+    gm_epnp5(ms1, ms2, P.cam, rvec, tvec, ws, sub);
+    for (int i = 0; i < 3; i++) { model[2 * i] = rvec[i]; model[2 * i + 1] = tvec[i]; }
     return 1;
   }
   struct Scorer {
@@ -1408,6 +1449,7 @@ __device__ GL_NOINLINE int em_solve5(const double* q1, const double* q2, double*
 }
 
 struct EModel {
+  static constexpr int LANES = 1;
   static constexpr bool SEQ_SCORE = false;   // score all hypotheses of a round, then replay (geom.hip)
   static constexpr int MP = 5, MAXM = 10, MS = 9, PT1 = 2, PT2 = 2;
   static constexpr int CH = 64, WS = 0;  // initialisation only (src/initializer.cpp), not on the per-frame path: private memory
