@@ -67,7 +67,8 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--contexts", type=int, default=4, help="contexts per GPU, stepped asynchronously")
-    ap.add_argument("--batch", type=int, default=256, help="independent camera streams per context")
+    ap.add_argument("--batch", type=int, default=None, help="independent camera streams per context (default: 512 up to 1280x720, 256 above: "
+                    "the frame rings of 4 contexts x 61 frames then take 115 GB / 129 GB of the 288 GB)")
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--nfeatures", type=int, default=2000)
@@ -325,6 +326,8 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from ros2_mono_vo_amd import parallel, synth
 
+    if args.batch is None:
+        args.batch = 512 if args.width * args.height <= 1280 * 720 else 256
     W, H, B, C, K, Wm = args.width, args.height, args.batch, args.contexts, args.steps, args.warmup
     K2 = args.ingest_steps if solo else 0
     K3 = args.extra_steps
@@ -363,19 +366,10 @@ def main():
     t_setup = time.perf_counter()
     bank = synth_gpu.SceneBank(dev)
     pitch = (W + 63) // 64 * 64
-    frames = torch.zeros((C, n_frames, B, H, pitch), dtype=torch.uint8, device=dev)     # ring layout of a context: [frame][slot][H][pitch]
     cpu_n = 0
     if cpu_on:
         cpu_n = min(B, args.cpu_streams if args.cpu_streams is not None else min(cores, 64))
-    depth_dev = torch.zeros((C, B, H, W), dtype=torch.float32, device=dev)               # depth of frame 0: the seed landmarks
     seed0 = 0x5EED0003 + 100003 * rank
-    for c in range(C):
-        for s in range(B):
-            prm = bank.stream_params(seed0 + 1009 * c + s)
-            fr, d0 = synth_gpu.render_stream(bank, prm, Kmat, W, H, n_frames)
-            frames[c, :, s, :, :W] = fr
-            depth_dev[c, s] = d0
-    torch.cuda.synchronize()
     # the CPU timing stream: stream 0 of context 0 continued to --cpu-frames frames (+ 20 of warm-up)
     cpu_long = None
     if cpu_on:
@@ -387,38 +381,46 @@ def main():
         fr, d0 = synth_gpu.render_stream(bank, bank.stream_params(seed0), Kmat, W, H, 1 + 2 * args.single_steps)
         single = (fr.cpu().numpy(), d0.cpu().numpy())
 
-    # ---- contexts: frames resident in the device ring, seeded with depth landmarks -------------------------------------
-    ctxs = []
+    # ---- contexts, one at a time: render its B streams in the ring's layout ([frame][slot][H][pitch]), copy them into the
+    # context's device ring, seed with depth landmarks, keep the host copies the later phases need, drop the staging tensor
+    # (so the peak is the rings + ONE context's staging copy: 4 x 512 streams x 61 frames is 115 GB of rings)
+    ctxs, pins = [], []
+    cpu_frames = depth0 = None
+    ing0 = [1 + offs[c] + n_main for c in range(C)]                                     # first frame of the ingest phase per context
     shared = [torch.cuda.Stream(device=dev) for _ in range(args.compute_streams)]       # kept alive for the run
     mk = lambda c: Context(max_width=W, max_height=H, batch=B, nfeatures=args.nfeatures, max_points=maxpts, ring_frames=n_frames, device=local_rank,
                            **({"hip_stream": shared[c % len(shared)].cuda_stream} if shared else {}))
     pre = [mk(c) for c in range(C)] if args.contexts_first else None     # diagnostic: creation order must not matter
     for c in range(C):
+        frames = torch.zeros((n_frames, B, H, pitch), dtype=torch.uint8, device=dev)
+        depth_dev = torch.zeros((B, H, W), dtype=torch.float32, device=dev)              # depth of frame 0: the seed landmarks
+        for s in range(B):
+            prm = bank.stream_params(seed0 + 1009 * c + s)
+            fr, d0 = synth_gpu.render_stream(bank, prm, Kmat, W, H, n_frames)
+            frames[:, s, :, :W] = fr
+            depth_dev[s] = d0
+        torch.cuda.synchronize()
         ctx = pre[c] if pre else mk(c)
         ctx.batch_set_intrinsics(Kmat, dcoef)
         for f in range(n_frames):
-            ctx.batch_upload_async(f, frames[c, f].data_ptr(), W, H, pitch, H * pitch)     # device -> device, one copy per frame
+            ctx.batch_upload_async(f, frames[f].data_ptr(), W, H, pitch, H * pitch)     # device -> device, one copy per frame
         ctx.sync()
         ctx.batch_seed(0)
-        dc = depth_dev[c].cpu().numpy()
+        dc = depth_dev.cpu().numpy()
         for s in range(B):
             ctx.batch_set_landmarks(s, synth_gpu.depth_landmarks(Kmat, dc[s], ctx.batch_get_tracks(s)))
         ctxs.append(ctx)
-    depth0 = depth_dev[0, :max(cpu_n, 1)].cpu().numpy()     # host copies only of what the CPU legs need
-    del depth_dev, dc
-    # frames of the ingest phase go to pinned host memory; CPU-oracle streams are downloaded; then the device copy is dropped
-    cpu_frames = frames[0, :1 + offs[0] + n_main, :cpu_n, :, :W].permute(1, 0, 2, 3).contiguous().cpu().numpy() if cpu_n else None
-    if args.dump_stream is not None and rank == 0:
-        np.savez_compressed(args.dump_path, frames=frames[0, :1 + n_main, args.dump_stream, :, :W].cpu().numpy(),
-                            depth0=depth0[min(args.dump_stream, len(depth0) - 1)], K=Kmat)
-    ing0 = [1 + offs[c] + n_main for c in range(C)]                                     # first frame of the ingest phase per context
-    pins = []
-    if K2:
-        for c in range(C):
-            pin = ctxs[c].host_alloc(K2 * B * H * pitch).reshape(K2, B, H, pitch)
-            pin[:] = frames[c, ing0[c]:ing0[c] + K2].cpu().numpy()
+        if c == 0:
+            depth0 = dc[:max(cpu_n, 1)].copy()              # host copies only of what the CPU legs need
+            cpu_frames = frames[:1 + offs[0] + n_main, :cpu_n, :, :W].permute(1, 0, 2, 3).contiguous().cpu().numpy() if cpu_n else None
+            if args.dump_stream is not None and rank == 0:
+                np.savez_compressed(args.dump_path, frames=frames[:1 + n_main, args.dump_stream, :, :W].cpu().numpy(),
+                                    depth0=depth0[min(args.dump_stream, len(depth0) - 1)], K=Kmat)
+        if K2:                                                # frames of the ingest phase go to pinned host memory
+            pin = ctx.host_alloc(K2 * B * H * pitch).reshape(K2, B, H, pitch)
+            pin[:] = frames[ing0[c]:ing0[c] + K2].cpu().numpy()
             pins.append(pin)
-    del frames
+        del frames, depth_dev, dc
     torch.cuda.empty_cache()
     t_setup = time.perf_counter() - t_setup
 

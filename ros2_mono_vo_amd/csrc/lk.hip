@@ -140,6 +140,8 @@ struct Pyr3Args {
   const u8* src; size_t src_stride; int w0, h0, p0;   // level 0 (e.g. a ring entry), slots src_stride apart
   u8* l1; u8* l2; u8* l3; size_t dst_stride;          // levels 1..3 of the pyramid set
   int w1, h1, p1, w2, h2, p2, w3, h3, p3;
+  int lim1, lim2;                                     // 16-byte stores of levels 1 / 2 start below this column (w rounded up to 16: the
+                                                      // excess lands in the plane's right border, which lk_border_kernel rewrites)
   TileGrid tg;                                        // tiles of 16 x 16 level-3 pixels x slots
 };
 
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(256) void pyr3_kernel(Pyr3Args A) {
   {
     const int row = tid >> 2, q = tid & 3;
     const int y = 64 * by + row, x = 64 * bx + 16 * q;
-    if (y < A.h1 && x < A.p1) {
+    if (y < A.h1 && x < A.lim1) {
       const unsigned* r = t1 + (6 + row) * P3_T1_PD + 2 + 4 * q;   // byte index 8 = column 64 bx
       *(uint4*)(A.l1 + (size_t)bz * A.dst_stride + (size_t)__umul24(y, A.p1) + x) = make_uint4(r[0], r[1], r[2], r[3]);
     }
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256) void pyr3_kernel(Pyr3Args A) {
   if (tid < 64) {
     const int row = tid >> 1, q = tid & 1;
     const int y = 32 * by + row, x = 32 * bx + 16 * q;
-    if (y < A.h2 && x < A.p2) {
+    if (y < A.h2 && x < A.lim2) {
       const unsigned* r = t2 + (2 + row) * P3_T2_PD + 1 + 4 * q;   // byte index 4 = column 32 bx
       *(uint4*)(A.l2 + (size_t)bz * A.dst_stride + (size_t)__umul24(y, A.p2) + x) = make_uint4(r[0], r[1], r[2], r[3]);
     }
@@ -264,6 +266,55 @@ __global__ __launch_bounds__(256) void pyr3_kernel(Pyr3Args A) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// borders of the level planes
+// ---------------------------------------------------------------------------------------------------
+// One launch after the pyramid of a set is built: levels 1.. of every slot get the reflect-101 border that
+// cv::buildOpticalFlowPyramid gives its levels and calcOpticalFlowPyrLK's windows read when they hang over the edge
+// (MVO_LK_PAD rows above and below, MVO_LK_PAD columns on the left, MVO_LK_PADR on the right), so that lk_track_kernel's
+// 16-byte tile loads never need their per-byte border path at these levels.  A thread writes one dword of the border: the
+// top and bottom bands are full plane rows, the side bands 8 + nr dwords per image row, where the right band starts at the
+// dword holding column w (its in-image bytes get their own value back).  Reads touch pixels inside the image only
+// (reflected coordinates), writes only the border: no ordering between threads is needed.
+struct LkBorderArgs {
+  u8* img[MVO_LK_MAX_LEVELS - 1];
+  int w[MVO_LK_MAX_LEVELS - 1], h[MVO_LK_MAX_LEVELS - 1], pitch[MVO_LK_MAX_LEVELS - 1];
+  int first[MVO_LK_MAX_LEVELS];   // first border dword of a level in the launch's linear index; [nlev] = total
+  int nlev;
+  size_t img_stride;
+};
+
+__global__ __launch_bounds__(256) void lk_border_kernel(LkBorderArgs A) {
+  int i = blockIdx.x * 256 + threadIdx.x, k = 0;
+  if (i >= A.first[A.nlev]) return;
+  while (k + 1 < A.nlev && i >= A.first[k + 1]) k++;
+  i -= A.first[k];
+  const int w = A.w[k], h = A.h[k], pitch = A.pitch[k];
+  const int pd = (MVO_LK_PAD + w + MVO_LK_PADR) >> 2;             // dwords per plane row that are written
+  const int xr = w & ~3, nr = (w + MVO_LK_PADR - xr) >> 2;        // right band: first column, dwords
+  const int band = 2 * MVO_LK_PAD * pd;
+  int x0, y;
+  if (i < band) {                                                  // top / bottom rows
+    const int r = i / pd;
+    x0 = -MVO_LK_PAD + 4 * (i - r * pd);
+    y = r < MVO_LK_PAD ? r - MVO_LK_PAD : h + (r - MVO_LK_PAD);
+  } else {                                                         // left / right columns of the image rows
+    const int per = MVO_LK_PAD / 4 + nr, j = i - band;
+    y = j / per;
+    const int c = j - y * per;
+    x0 = c < MVO_LK_PAD / 4 ? -MVO_LK_PAD + 4 * c : xr + 4 * (c - MVO_LK_PAD / 4);
+  }
+  u8* img = A.img[k] + (size_t)blockIdx.y * A.img_stride;
+  const u8* rp = img + (ptrdiff_t)d_reflect101(y, h) * pitch;
+  unsigned v = 0;
+#pragma unroll
+  for (int b = 0; b < 4; b++) v |= (unsigned)rp[d_reflect101(x0 + b, w)] << (8 * b);
+  *(unsigned*)(img + (ptrdiff_t)y * pitch + x0) = v;
+}
+
+static void lk_launch_border(mvo_ctx* ctx, int set, const LkLevels& L, int nslots, hipStream_t st);
+
 // ---------------------------------------------------------------------------------------------------
 // LK tracker
 // ---------------------------------------------------------------------------------------------------
@@ -272,6 +323,7 @@ struct LkLevelDesc {
   const u8* J;  // next image
   size_t stride;  // bytes between slots at this level (both images): level 0 may live in the frame ring, levels 1.. in the pyramid sets
   int w, h, pitch;
+  int pad;        // rows / columns of reflect-101 border around both images (0: level 0 in the frame ring; MVO_LK_PAD: a pyramid plane)
 };
 struct LkArgs {
   LkLevelDesc lv[MVO_LK_MAX_LEVELS];
@@ -381,10 +433,12 @@ __device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1)
 // the same for 4 or 16 bytes), the tile starts `shift` bytes into each LDS row.  Border path: one dword of a tile row per
 // item, the image row by reflect-101, the four columns from two aligned dwords when they lie inside the image and per
 // byte by reflect-101 otherwise; the tile then starts at byte 0.  Returns the byte shift (uniform over the row).
+// `pad`: rows / columns of reflect-101 border the plane carries around the image (the fast path then covers every tile the
+// tracker can ask for: window origins lie in [-21, w) x [-21, h), search tiles 5 further out).
 template <int ROWS, int TW, int PD, int NX4>
-__device__ __forceinline__ int lk_load_tile16(unsigned* lds, const u8* __restrict__ img, int w, int h, int pitch, int x0, int y0, int l) {
+__device__ __forceinline__ int lk_load_tile16(unsigned* lds, const u8* __restrict__ img, int w, int h, int pitch, int pad, int x0, int y0, int l) {
   const int xa = x0 & ~3;
-  const bool inside = x0 >= 0 && y0 >= 0 && x0 + TW <= w && y0 + ROWS <= h && xa + 16 * NX4 <= pitch;
+  const bool inside = x0 >= -pad && y0 >= -pad && x0 + TW <= w + pad && y0 + ROWS <= h + pad && xa + pad + 16 * NX4 <= pitch;
   if (inside) {
     const u8* base = img + (size_t)y0 * pitch + xa;
 #pragma unroll
@@ -468,6 +522,9 @@ __device__ __forceinline__ void lk_track_group(const LkArgs& A, LkGroupLds& S, c
   int status = 1;
   float errv = 0.f;
   float sx = 0.f, sy = 0.f;  // nextPts[ptidx] as stored by OpenCV between levels
+#ifdef LK_ITER_STATS   // experiment builds only (tools/build_variant.sh): err = own iterations + 1000 * loop trips of the wavefront
+  int st_own = 0, st_trips = 0;
+#endif
 
   for (int level = A.nlevels - 1; level >= 0; level--) {
     const LkLevelDesc lv = A.lv[level];
@@ -490,7 +547,7 @@ __device__ __forceinline__ void lk_track_group(const LkArgs& A, LkGroupLds& S, c
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();   // the search tile of the previous level shares this memory
     int shI = 0;
-    if (go) shI = lk_load_tile16<LK_IT, LK_IT, LK_IP / 4, 2>(S.s.it, I, lv.w, lv.h, lv.pitch, ipx - 1, ipy - 1, l);
+    if (go) shI = lk_load_tile16<LK_IT, LK_IT, LK_IP / 4, 2>(S.s.it, I, lv.w, lv.h, lv.pitch, lv.pad, ipx - 1, ipy - 1, l);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // ---- Scharr field on the 22x22 window-source positions (zero outside the image) --------------
@@ -632,6 +689,9 @@ __device__ __forceinline__ void lk_track_group(const LkArgs& A, LkGroupLds& S, c
     bool iter = go;
     for (int j = 0; j < A.max_count; j++) {
       if (!__any(iter)) break;
+#ifdef LK_ITER_STATS
+      st_trips++; st_own += iter ? 1 : 0;
+#endif
       if (iter) {
         const int inx = d_cv_floor(nx), iny = d_cv_floor(ny);
         if (inx < -LK_WIN || inx >= lv.w || iny < -LK_WIN || iny >= lv.h) {
@@ -643,7 +703,7 @@ __device__ __forceinline__ void lk_track_group(const LkArgs& A, LkGroupLds& S, c
             jx0 = inx - LK_JSLACK; jy0 = iny - LK_JSLACK;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            shJ = lk_load_tile16<LK_JT, LK_JT, LK_JP / 4, 3>(S.jt, J, lv.w, lv.h, lv.pitch, jx0, jy0, l);
+            shJ = lk_load_tile16<LK_JT, LK_JT, LK_JP / 4, 3>(S.jt, J, lv.w, lv.h, lv.pitch, lv.pad, jx0, jy0, l);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             have_tile = true;
@@ -695,7 +755,7 @@ __device__ __forceinline__ void lk_track_group(const LkArgs& A, LkGroupLds& S, c
           jx0 = inx - LK_JSLACK; jy0 = iny - LK_JSLACK;
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
-          shJ = lk_load_tile16<LK_JT, LK_JT, LK_JP / 4, 3>(S.jt, J, lv.w, lv.h, lv.pitch, jx0, jy0, l);
+          shJ = lk_load_tile16<LK_JT, LK_JT, LK_JP / 4, 3>(S.jt, J, lv.w, lv.h, lv.pitch, lv.pad, jx0, jy0, l);
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           ddx = LK_JSLACK; ddy = LK_JSLACK;
@@ -725,6 +785,9 @@ __device__ __forceinline__ void lk_track_group(const LkArgs& A, LkGroupLds& S, c
     A.next_pts[2 * pidx + 1] = sy;
     A.status[pidx] = (u8)status;
     A.err[pidx] = errv;
+#ifdef LK_ITER_STATS
+    A.err[pidx] = (float)(st_own + 1000 * st_trips);
+#endif
   }
 }
 
@@ -742,7 +805,7 @@ __device__ __forceinline__ void lk_track_group(const LkArgs& A, LkGroupLds& S, c
 #define LK_RESIDENT_PER_CU (4 * LK_WAVES_PER_EU)
 #endif
 __global__ __launch_bounds__(64, LK_WAVES_PER_EU) void lk_track_kernel(LkArgs A) {
-  __shared__ LkGroupLds lds[LK_G];
+  __shared__ __attribute__((aligned(16))) LkGroupLds lds[LK_G];
 #if LK_PRIO > 0
   __builtin_amdgcn_s_setprio(LK_PRIO);   // issue priority over other contexts' image kernels that share the SIMD (the RANSAC chains use 3)
 #endif
@@ -790,11 +853,29 @@ static ImgSet lk_imgset(mvo_ctx* ctx, int set, const LkLevels& L, int level) {
   if (level == 0) {   // the per-call API's own level 0: slot 0 only (the frame-batch tracker reads level 0 in the frame ring)
     s.base = ctx->lk_l0[set];
     s.slot_stride = 0;
-  } else {
-    s.base = ctx->lk_mem[set] + ctx->lk_level_off[level];
+  } else {   // pixel (0, 0) of the bordered plane
+    s.base = ctx->lk_mem[set] + ctx->lk_level_off[level] + (size_t)MVO_LK_PAD * s.pitch + MVO_LK_PAD;
     s.slot_stride = ctx->lk_slot_bytes;
   }
   return s;
+}
+static void lk_launch_border(mvo_ctx* ctx, int set, const LkLevels& L, int nslots, hipStream_t st) {
+  if (L.n < 2) return;
+  LkBorderArgs A;
+  memset(&A, 0, sizeof(A));
+  int total = 0;
+  for (int l = 1; l < L.n; l++) {
+    const int k = l - 1;
+    ImgSet s = lk_imgset(ctx, set, L, l);
+    A.img[k] = s.base; A.w[k] = s.w; A.h[k] = s.h; A.pitch[k] = s.pitch;
+    A.first[k] = total;
+    const int pd = (MVO_LK_PAD + s.w + MVO_LK_PADR) >> 2, nr = (s.w + MVO_LK_PADR - (s.w & ~3)) >> 2;
+    total += 2 * MVO_LK_PAD * pd + s.h * (MVO_LK_PAD / 4 + nr);
+  }
+  A.first[L.n - 1] = total;
+  A.nlev = L.n - 1;
+  A.img_stride = ctx->lk_slot_bytes;
+  hipLaunchKernelGGL(lk_border_kernel, dim3((total + 255) / 256, nslots), dim3(256), 0, st, A);
 }
 
 // Build levels 1.. of pyramid set `set` for `nslots` slots.  Level 0 is `l0` (slots `l0_stride` bytes apart, e.g. an entry of
@@ -811,8 +892,10 @@ int lk_build_pyramid(mvo_ctx* ctx, int set, const LkLevels& L, int nslots, hipSt
     A.dst_stride = ctx->lk_slot_bytes;
     A.w1 = L.w[1]; A.h1 = L.h[1]; A.p1 = L.pitch[1]; A.w2 = L.w[2]; A.h2 = L.h[2]; A.p2 = L.pitch[2];
     A.w3 = L.w[3]; A.h3 = L.h[3]; A.p3 = L.pitch[3];
+    A.lim1 = align_up(L.w[1], 16); A.lim2 = align_up(L.w[2], 16);
     A.tg = TileGrid{(L.w[3] + 15) / 16, (L.h[3] + 15) / 16, nslots};
     hipLaunchKernelGGL(pyr3_kernel, dim3(xcd_grid_blocks(A.tg)), dim3(256), 0, st, A);
+    lk_launch_border(ctx, set, L, nslots, st);
     return MVO_OK;
   }
   for (int l = 1; l < L.n; l++) {
@@ -820,6 +903,7 @@ int lk_build_pyramid(mvo_ctx* ctx, int set, const LkLevels& L, int nslots, hipSt
     if (l == 1 && l0) { src.base = const_cast<u8*>(l0); src.slot_stride = l0_stride; }
     launch_pyrdown(ctx, src, lk_imgset(ctx, set, L, l), nslots, st);
   }
+  lk_launch_border(ctx, set, L, nslots, st);
   return MVO_OK;
 }
 
@@ -835,6 +919,7 @@ int lk_track_device(mvo_ctx* ctx, int prev_set, int cur_set, const LkLevels& L, 
     ImgSet p = lk_imgset(ctx, prev_set, L, l), c = lk_imgset(ctx, cur_set, L, l);
     A.lv[l].I = p.base; A.lv[l].J = c.base; A.lv[l].stride = p.slot_stride;
     A.lv[l].w = L.w[l]; A.lv[l].h = L.h[l]; A.lv[l].pitch = L.pitch[l];
+    A.lv[l].pad = l ? MVO_LK_PAD : 0;
   }
   if (prev_l0 && cur_l0) { A.lv[0].I = prev_l0; A.lv[0].J = cur_l0; A.lv[0].stride = l0_stride; }
   A.nlevels = L.n;

@@ -50,7 +50,8 @@ LkLevels lk_levels(int w, int h, int win, int max_level) {
   for (int l = 1; l <= max_level && l < MVO_LK_MAX_LEVELS; l++) {
     int sw = (L.w[l - 1] + 1) / 2, sh = (L.h[l - 1] + 1) / 2;
     if (sw <= win || sh <= win) break;  // buildOpticalFlowPyramid early stop
-    L.w[l] = sw; L.h[l] = sh; L.pitch[l] = align_up(sw, 64);
+    // levels >= 1 live in planes with a border: pixel (0, 0) sits MVO_LK_PAD rows and columns into the plane
+    L.w[l] = sw; L.h[l] = sh; L.pitch[l] = align_up(sw + MVO_LK_PAD + MVO_LK_PADR, 64);
     L.n = l + 1;
   }
   return L;
@@ -119,7 +120,7 @@ static int mvo_create_impl(const mvo_config* cfg, mvo_ctx** out) {
   size_t off = 0;
   for (int l = 1; l < MVO_LK_MAX_LEVELS; l++) {
     ctx->lk_level_off[l] = off;
-    if (l < L.n) off += (size_t)L.pitch[l] * L.h[l];
+    if (l < L.n) off += (size_t)L.pitch[l] * (L.h[l] + 2 * MVO_LK_PAD);
     off = (off + 255) & ~(size_t)255;
   }
   ctx->lk_slot_bytes = off + 256;

@@ -31,6 +31,8 @@ struct ImgSet {
 };
 
 #define MVO_LK_MAX_LEVELS 4
+#define MVO_LK_PAD 32          // border rows (top, bottom) and columns (left) of a pyramid level plane >= 1
+#define MVO_LK_PADR 48         // border columns on the right of a level plane: 32 + the over-read of the 16-byte tile loads
 #define MVO_ORB_LEVELS 8
 
 struct mvo_ctx {
@@ -46,7 +48,8 @@ struct mvo_ctx {
   int maxw = 0, maxh = 0, maxpts = 0;
 
   // ---- LK: two pyramid sets (ping-pong "prev"/"cur") --------------------------------------------
-  u8* lk_mem[2] = {nullptr, nullptr};   // levels 1.. of every slot, packed per slot
+  u8* lk_mem[2] = {nullptr, nullptr};   // levels 1.. of every slot, packed per slot; every level plane carries a reflect-101 border
+                                        // (MVO_LK_PAD rows / columns, MVO_LK_PADR columns on the right), see lk_levels()
   u8* lk_l0[2] = {nullptr, nullptr};    // level 0 of slot 0 only: the per-call API (mvo_lk_track, mvo_pyrdown).  The frame-batch
                                         // tracker reads level 0 in place from the frame ring and keeps no copy of it.
   size_t lk_slot_bytes = 0;
