@@ -1,7 +1,7 @@
 """Experiment: how much of lk_track_kernel's iteration loop is lost to the four points of a wavefront finishing at different
 times.  Needs a variant build: `tools/build_variant.sh iters -DLK_ITER_STATS`, then
 `MVO_LIB=build/libmvo_iters.so python3 profiles/tools/lk_iter_stats.py`.  The variant returns, in `err`, own iterations +
-1000 * loop trips of the point's wavefront (summed over the four levels).  Points go in groups of four in the order given:
+100 * loop trips of the point's wavefront + 10000 * search-tile loads (summed over the four levels).  Points go in groups of four in the order given:
 ORB order, Morton order (the tracker's work list), and Morton order refined by the own-iteration count of the PREVIOUS frame
 pair (what a tracker could carry along)."""
 import os, sys, json
@@ -27,7 +27,9 @@ def morton(xy, shift=4):
 
 def run(ctx, a, b, pts):
     out, st, err = ctx.lk_track(a, b, pts)
-    own = (err % 1000).astype(np.int64); trips = (err // 1000).astype(np.int64)
+    e = err.astype(np.int64)
+    own = e % 100; trips = (e // 100) % 100
+    run.jloads = getattr(run, "jloads", 0) + int((e // 10000).sum()); run.points = getattr(run, "points", 0) + len(e)
     return out, st, own, trips
 
 
@@ -53,4 +55,5 @@ with Context(max_width=W, max_height=H, max_points=8192) as ctx:
             tot[name][0] += int(own[:n4].sum()); tot[name][1] += int(trips[:n4].sum())
     for name, (own, trips) in tot.items():
         res[name] = {"own_iterations": own, "wave_trips_x_rows": trips, "efficiency": round(own / trips, 4)}
+res["search_tile_loads_per_point"] = round(run.jloads / run.points, 3)
 print(json.dumps(res, indent=1))

@@ -435,7 +435,10 @@ __device__ __forceinline__ void ransac_slot(const RansacArgs& A, const int slot)
         for (int i = 0; i < M::MP; i++) s_idx[e][i] = keep[j][i];
       if (tid == 0) s_qn = left;
       __syncthreads();
-    } else if (tid == 0) s_qn = 0;   // a round without over-draw consumes what it drew (or the loop has ended)
+    } else {   // a round without over-draw consumes what it drew (or the loop has ended)
+      if (tid == 0) s_qn = 0;
+      if (NW > 1) __syncthreads();   // the other wavefronts read s_qn at the top of the next round (uniform: NW is a template constant)
+    }
   }
   // ---- consensus mask of the winning model ---------------------------------------------------------------------
   if (lmeds) {

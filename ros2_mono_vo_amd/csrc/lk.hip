@@ -340,16 +340,14 @@ struct LkArgs {
   double min_eig;
   // device-driven launch (frame-batch tracker): the points of all slots form one dense work list,
   // work_slot[w] = slot << 16 | point of item w, pt_base[slot] = first item of the slot, pt_base[nslots] = item count; persistent
-  // wavefronts claim four items at a time (one per DPP row) from the eight counters work_ctr[0..8) (one per XCD part of the
-  // list, zeroed before the launch).  Null: points blockIdx.x * 4 .. + 3 of slot blockIdx.y with the host-sized grid.
+  // wavefronts claim four items at a time (one per DPP row) from the counter work_ctr[0] (zeroed before the launch); with
+  // work_ctr null, workgroup b takes items 4 b .. 4 b + 3 and leaves (the grid covers the list).  work_slot null: points
+  // blockIdx.x * 4 .. + 3 of slot blockIdx.y with the host-sized grid.
   const int* work_slot;
   const int* pt_base;
   int* work_ctr;
   int nslots;
 };
-#ifndef LK_PARTS
-#define LK_PARTS 1   // parts of the work list: 8 = one per XCD (5.6x less HBM traffic, but 9-15 % slower: see DESIGN.md)
-#endif
 
 #define LK_WIN 21
 #define LK_IT 24          // I tile edge (WIN + 1 bilinear + 2 Scharr halo)
@@ -522,8 +520,8 @@ __device__ __forceinline__ void lk_track_group(const LkArgs& A, LkGroupLds& S, c
   int status = 1;
   float errv = 0.f;
   float sx = 0.f, sy = 0.f;  // nextPts[ptidx] as stored by OpenCV between levels
-#ifdef LK_ITER_STATS   // experiment builds only (tools/build_variant.sh): err = own iterations + 1000 * loop trips of the wavefront
-  int st_own = 0, st_trips = 0;
+#ifdef LK_ITER_STATS   // experiment builds only (tools/build_variant.sh): err = own iterations + 100 * loop trips of the wavefront + 10000 * search-tile loads
+  int st_own = 0, st_trips = 0, st_jl = 0;
 #endif
 
   for (int level = A.nlevels - 1; level >= 0; level--) {
@@ -704,6 +702,9 @@ __device__ __forceinline__ void lk_track_group(const LkArgs& A, LkGroupLds& S, c
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             shJ = lk_load_tile16<LK_JT, LK_JT, LK_JP / 4, 3>(S.jt, J, lv.w, lv.h, lv.pitch, lv.pad, jx0, jy0, l);
+#ifdef LK_ITER_STATS
+            st_jl++;
+#endif
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             have_tile = true;
@@ -786,7 +787,7 @@ __device__ __forceinline__ void lk_track_group(const LkArgs& A, LkGroupLds& S, c
     A.status[pidx] = (u8)status;
     A.err[pidx] = errv;
 #ifdef LK_ITER_STATS
-    A.err[pidx] = (float)(st_own + 1000 * st_trips);
+    A.err[pidx] = (float)(st_own + 100 * st_trips + 10000 * st_jl);
 #endif
   }
 }
@@ -811,37 +812,40 @@ __global__ __launch_bounds__(64, LK_WAVES_PER_EU) void lk_track_kernel(LkArgs A)
 #endif
   const int lane = threadIdx.x, g = lane >> 4, l = lane & 15;
   LkGroupLds& S = lds[g];
-  if (A.work_slot) {
-    // The list is slot major.  With LK_PARTS = 8 it is cut into contiguous parts, one per XCD (workgroups go to the XCDs
-    // round-robin by linear id, so blockIdx.x & 7 is the XCD - a speed hint only): an XCD then walks whole slots and both
-    // pyramids of a slot (2.4 MB at 720p) stay in ITS 4 MB L2, instead of every XCD fetching every slot's lines.  A
-    // wavefront whose part has run dry helps with the next ones.
-    const int total = min(max(A.pt_base[A.nslots], 0), A.nslots * A.maxpts);
-    const int home = blockIdx.x % LK_PARTS;
-    for (int k = 0; k < LK_PARTS; k++) {   // every wavefront leaves once all counters have passed their parts
-      const int part = (home + k) % LK_PARTS;
-      const int lo = (int)((long long)total * part / LK_PARTS), hi = (int)((long long)total * (part + 1) / LK_PARTS);
-      for (;;) {
-        int w0 = 0;
-        if (lane == 0) w0 = atomicAdd(A.work_ctr + part, LK_G);
-        w0 = lo + __builtin_amdgcn_readfirstlane(w0);
-        if (w0 >= hi) break;
-        const int w = w0 + g;
-        bool valid = w < hi;
-        const int item = valid ? A.work_slot[w] : 0;   // slot << 16 | point (the slot's items in an order of the caller's choice)
-        const int slot = min(max(item >> 16, 0), A.nslots - 1);
-        const int p = item & 0xFFFF;
-        valid = valid && p < A.maxpts;   // always true for a consistent list
-        lk_track_group(A, S, slot, p, valid, l);
+  // One inlined copy of lk_track_group serves the three launch forms: persistent wavefronts claiming groups of four items
+  // from work_ctr, one workgroup per group of the list (work_ctr null), and the host-sized grid of the per-call API.
+  const bool list = A.work_slot != nullptr, persistent = list && A.work_ctr != nullptr;
+  const int total = list ? min(max(A.pt_base[A.nslots], 0), A.nslots * A.maxpts) : 0;
+  int next = blockIdx.x * LK_G;   // non-persistent list form: this workgroup's group; the LAST workgroup goes on to any groups
+                                  // beyond the grid (a caller's bound on the list that turned out too small costs time, not points)
+  for (;;) {
+    int slot, p;
+    bool valid;
+    if (list) {
+      int w0 = next;
+      if (persistent) {
+        if (lane == 0) w0 = atomicAdd(A.work_ctr, LK_G);
+        w0 = __builtin_amdgcn_readfirstlane(w0);
       }
+      if (w0 >= total) return;
+      const int w = w0 + g;
+      valid = w < total;
+      const int item = valid ? A.work_slot[w] : 0;   // slot << 16 | point (the slot's items in an order of the caller's choice)
+      slot = min(max(item >> 16, 0), A.nslots - 1);
+      p = item & 0xFFFF;
+      valid = valid && p < A.maxpts;   // always true for a consistent list
+    } else {
+      slot = blockIdx.y;
+      p = blockIdx.x * LK_G + g;
+      valid = p < min(A.npts[slot], A.maxpts);
+      if (!__any(valid)) return;
     }
-    return;
+    lk_track_group(A, S, slot, p, valid, l);
+    if (!persistent) {
+      if (!list || blockIdx.x != gridDim.x - 1) return;
+      next += LK_G;
+    }
   }
-  const int slot = blockIdx.y;
-  const int p = blockIdx.x * LK_G + g;
-  const bool valid = p < min(A.npts[slot], A.maxpts);
-  if (!__any(valid)) return;
-  lk_track_group(A, S, slot, p, valid, l);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -910,7 +914,8 @@ int lk_build_pyramid(mvo_ctx* ctx, int set, const LkLevels& L, int nslots, hipSt
 // Track d_prev_pts -> d_next_pts for `nslots` slots between pyramid sets prev_set and cur_set; `prev_l0` / `cur_l0` (slots
 // `l0_stride` bytes apart) replace the sets' level 0 when given.
 int lk_track_device(mvo_ctx* ctx, int prev_set, int cur_set, const LkLevels& L, int nslots, int max_n, hipStream_t st,
-                    const int* d_work_slot, const int* d_pt_base, int* d_work_ctr, const u8* prev_l0, const u8* cur_l0, size_t l0_stride) {
+                    const int* d_work_slot, const int* d_pt_base, int* d_work_ctr, const u8* prev_l0, const u8* cur_l0, size_t l0_stride,
+                    int items_bound) {
   if (!st) st = ctx->stream;
   LkArgs A;
   memset(&A, 0, sizeof(A));
@@ -934,7 +939,15 @@ int lk_track_device(mvo_ctx* ctx, int prev_set, int cur_set, const LkLevels& L, 
   A.min_eig = ctx->cfg.lk_min_eig;
   if (d_work_slot) {
     // persistent single-wavefront workgroups, as many as stay resident (256 CUs x 4 SIMDs x LK_WAVES_PER_EU)
-    const unsigned want = ((unsigned)nslots * (unsigned)ctx->maxpts + LK_G - 1) / LK_G;
+    unsigned items = (unsigned)nslots * (unsigned)ctx->maxpts;
+    if (items_bound >= 0 && (unsigned)items_bound < items) items = (unsigned)items_bound;   // the caller knows an upper bound of the list
+    const unsigned want = (items + LK_G - 1) / LK_G;
+    static const bool persistent = !(getenv("MVO_LK_PERSISTENT") && atoi(getenv("MVO_LK_PERSISTENT")) == 0);
+    if (!persistent) {
+      A.work_ctr = nullptr;
+      if (want) hipLaunchKernelGGL(lk_track_kernel, dim3(want), dim3(64), 0, st, A);
+      return MVO_OK;
+    }
     const unsigned full = 256u * LK_RESIDENT_PER_CU;
     hipLaunchKernelGGL(lk_track_kernel, dim3(want < full ? want : full), dim3(64), 0, st, A);
     return MVO_OK;

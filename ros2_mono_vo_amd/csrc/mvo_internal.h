@@ -253,7 +253,7 @@ int lk_build_pyramid(mvo_ctx* ctx, int set, const LkLevels& L, int nslots, hipSt
                      size_t l0_stride = 0);
 int lk_track_device(mvo_ctx* ctx, int prev_set, int cur_set, const LkLevels& L, int nslots, int max_n, hipStream_t st = nullptr,
                     const int* d_work_slot = nullptr, const int* d_pt_base = nullptr, int* d_work_ctr = nullptr,
-                    const u8* prev_l0 = nullptr, const u8* cur_l0 = nullptr, size_t l0_stride = 0);
+                    const u8* prev_l0 = nullptr, const u8* cur_l0 = nullptr, size_t l0_stride = 0, int items_bound = -1);
 // ORB in three phases on ctx->stream so that a caller can put other GPU work beside the host-side selection:
 //   orb_detect_enqueue  pyramid, FAST+NMS, ordered compaction, async copy of the counts           (no host wait)
 //   orb_select          waits for the counts (capacity check, grid size), Harris, OpenCV's two retainBest passes per

@@ -695,8 +695,14 @@ __global__ __launch_bounds__(256) void ic_angle_kernel(const u8* __restrict__ py
                                                        const int* __restrict__ kp_base, const int* __restrict__ nact) {
   nsel = orb_nsel(nsel, kp_base, nact);
   const int lane = threadIdx.x & 63, sub = lane & 31;
-  for (int g0 = blockIdx.x * 8; g0 < nsel; g0 += gridDim.x * 8) {
-  const int k = g0 + (threadIdx.x >> 5);
+  // Key-points are dense per slot, and a slot's pyramid (2.9 MB at 720p) fits the 4 MB L2 of an XCD: the groups of eight go
+  // to the XCDs in contiguous eighths of the list (same walk as xcd_tile_b), so a patch row's 128-byte lines are fetched from
+  // HBM once instead of by every XCD that happens to hold a key-point of the slot.
+  const unsigned ngrp = ((unsigned)nsel + 7u) / 8u, gper = (ngrp + 7u) / 8u;
+  for (unsigned b = blockIdx.x; b < 8u * gper; b += gridDim.x) {
+  const unsigned grp = (b & 7u) * gper + (b >> 3);
+  if (grp >= ngrp) continue;
+  const int k = (int)grp * 8 + (threadIdx.x >> 5);
   const bool live = k < nsel;
   int m10 = 0, m01 = 0, ci = 0, l = 0, x0 = 0, y0 = 0;
   if (live) {
@@ -912,8 +918,11 @@ __global__ __launch_bounds__(256) void brief_kernel(const u8* __restrict__ blur,
   nsel = orb_nsel(nsel, kp_base, nact);
   s_pat[threadIdx.x] = pattern[threadIdx.x];
   const int h = threadIdx.x >> 5, byte = threadIdx.x & 31;
-  for (int g0 = blockIdx.x * 8; g0 < nsel; g0 += gridDim.x * 8) {   // block-uniform trip count
-  const int k = g0 + h;
+  const unsigned ngrp = ((unsigned)nsel + 7u) / 8u, gper = (ngrp + 7u) / 8u;   // XCD-contiguous walk: see ic_angle_kernel
+  for (unsigned b = blockIdx.x; b < 8u * gper; b += gridDim.x) {                // block-uniform trip count
+  const unsigned grp = (b & 7u) * gper + (b >> 3);
+  if (grp >= ngrp) continue;                                                    // block-uniform
+  const int k = (int)grp * 8 + h;
   const bool live = k < nsel;
   BriefRec r;
   r.off = 0; r.pitch = 0; r.a = 0.f; r.b = 0.f;
@@ -1207,12 +1216,12 @@ int orb_describe_enqueue(mvo_ctx* ctx, int w, int h, int nslots, bool describe, 
   {
     ProfScope ps(ctx, "orb_describe");
     const int* nul = nullptr;
-    hipLaunchKernelGGL(ic_angle_kernel, dim3((nsel + 7) / 8), dim3(256), 0, st, o->d_pyr, G, o->d_sel, nsel, o->d_cx, o->d_cy,
+    hipLaunchKernelGGL(ic_angle_kernel, dim3(8 * (((nsel + 7) / 8 + 7) / 8)), dim3(256), 0, st, o->d_pyr, G, o->d_sel, nsel, o->d_cx, o->d_cy,
                        o->d_cl, o->d_cslot, o->d_ch, o->d_icmask, o->d_kp, nul, nul);
     if (describe) {
       hipLaunchKernelGGL(brief_rec_kernel, dim3((nsel + 255) / 256), dim3(256), 0, st, G, o->d_sel, nsel, o->d_cl, o->d_cslot, o->d_kp,
                          (BriefRec*)o->d_brec, nul, nul);
-      hipLaunchKernelGGL(brief_kernel, dim3((nsel + 7) / 8), dim3(256), 0, st, o->d_blur,
+      hipLaunchKernelGGL(brief_kernel, dim3(8 * (((nsel + 7) / 8 + 7) / 8)), dim3(256), 0, st, o->d_blur,
                          (const BriefRec*)o->d_brec, nsel, o->d_pattern, o->d_desc, nul, nul);
     }
   }
@@ -1241,11 +1250,11 @@ int orb_run_device(mvo_ctx* ctx, int w, int h, int max_slots, const int* d_nact)
   {
     ProfScope ps(ctx, "orb_describe");
     const int cap = o->kp_cap;
-    hipLaunchKernelGGL(ic_angle_kernel, dim3(persist_grid((cap + 7) / 8)), dim3(256), 0, st, o->d_pyr, G, o->d_sel, cap, o->d_cx, o->d_cy,
+    hipLaunchKernelGGL(ic_angle_kernel, dim3(persist_grid(8 * (((cap + 7) / 8 + 7) / 8))), dim3(256), 0, st, o->d_pyr, G, o->d_sel, cap, o->d_cx, o->d_cy,
                        o->d_cl, o->d_cslot, o->d_ch, o->d_icmask, o->d_kp, (const int*)o->d_kp_base, d_nact);
     hipLaunchKernelGGL(brief_rec_kernel, dim3(persist_grid((cap + 255) / 256)), dim3(256), 0, st, G, o->d_sel, cap, o->d_cl, o->d_cslot,
                        o->d_kp, (BriefRec*)o->d_brec, (const int*)o->d_kp_base, d_nact);
-    hipLaunchKernelGGL(brief_kernel, dim3(persist_grid((cap + 7) / 8)), dim3(256), 0, st, o->d_blur, (const BriefRec*)o->d_brec, cap,
+    hipLaunchKernelGGL(brief_kernel, dim3(persist_grid(8 * (((cap + 7) / 8 + 7) / 8))), dim3(256), 0, st, o->d_blur, (const BriefRec*)o->d_brec, cap,
                        o->d_pattern, o->d_desc, (const int*)o->d_kp_base, d_nact);
   }
   return MVO_OK;

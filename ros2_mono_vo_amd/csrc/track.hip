@@ -707,17 +707,24 @@ static int trk_step_enqueue(mvo_ctx* ctx, int frame_idx) {
                        t->d_flags, t->d_res);
     hipLaunchKernelGGL(trk_worklist_sort_kernel, dim3(B), dim3(256), 0, st, t->d_pt_base, ctx->d_prev_pts, cap, t->d_work_slot);
   }
+  // upper bound of the work list, known on the host when the last step has been collected: a slot's track count is its n_tracks
+  int items_bound = -1;
+  if (t->res_valid && t->npending == 0) {
+    long long sum = 0;
+    for (int s = 0; s < B; s++) sum += std::min(std::max(t->last_res[s].n_tracks, 0), cap);
+    items_bound = (int)std::min<long long>(sum, (long long)B * cap);
+  }
   if (lk_turns()) {
     std::lock_guard<std::mutex> lock(g_lk_mu);
     hipEvent_t& last = lk_last(ctx);
     if (last && last != t->ev_lk) MVO_HIP(hipStreamWaitEvent(st, last, 0));
     { ProfScope ps(ctx, "lk_track");
-      lk_track_device(ctx, prev_set, cur_set, L, B, cap, st, t->d_work_slot, t->d_pt_base, t->d_work_ctr, ring_prev, ring_cur, p->frame_bytes); }
+      lk_track_device(ctx, prev_set, cur_set, L, B, cap, st, t->d_work_slot, t->d_pt_base, t->d_work_ctr, ring_prev, ring_cur, p->frame_bytes, items_bound); }
     MVO_HIP(hipEventRecord(t->ev_lk, st));
     last = t->ev_lk;
   } else {
     ProfScope ps(ctx, "lk_track");
-    lk_track_device(ctx, prev_set, cur_set, L, B, cap, st, t->d_work_slot, t->d_pt_base, t->d_work_ctr, ring_prev, ring_cur, p->frame_bytes);
+    lk_track_device(ctx, prev_set, cur_set, L, B, cap, st, t->d_work_slot, t->d_pt_base, t->d_work_ctr, ring_prev, ring_cur, p->frame_bytes, items_bound);
   }
   MVO_HIP(hipEventRecord(p->ev_rd[prev_entry], st));   // the previous frame's ring entry may be overwritten from here on
   p->rd_pending[prev_entry] = 1;

@@ -263,6 +263,30 @@ def test_lk_edge_cases(ctx720, frames480):
     _check_lk(ctx720, small, b[:101, :87], sp)
 
 
+@pytest.mark.parametrize("w,h", [(641, 363), (322, 243), (203, 179), (1279, 719)])
+def test_lk_windows_over_the_image_edge_every_level(w, h):
+    """Levels 1.. of the LK pyramid live in planes with a reflect-101 border (csrc/lk.hip lk_border_kernel) so that the tile
+    loads of windows hanging over the edge take the same 16-byte path as interior ones: points within a window of every
+    edge - at level 3 that is a band of ~100 pixels - on images whose level widths are not multiples of 4, with a flow that
+    pushes the search windows further out, must match the oracle bit for bit; the same context then serves a smaller
+    image (stale border pixels of the larger one must not leak in)."""
+    rng = np.random.default_rng(w * 131 + h)
+    base = synth.gen_stream(max(w, 640) + 40, max(h, 480) + 40, 0x5EED0321 + w, 2)
+    a = np.ascontiguousarray(base[0][10:10 + h, 12:12 + w])
+    b = np.ascontiguousarray(base[1][13:13 + h, 7:7 + w])      # + a global shift of (5, -3)
+    xs = np.concatenate([rng.uniform(-3, 26, 150), rng.uniform(w - 26, w + 3, 150), rng.uniform(0, w, 300)])
+    ys = np.concatenate([rng.uniform(0, h, 300), rng.uniform(-3, 26, 150), rng.uniform(h - 26, h + 3, 150)])
+    ring = np.stack([xs, ys], 1).astype(np.float32)
+    wide = np.stack([rng.uniform(0, w, 400), rng.uniform(0, h, 400)], 1).astype(np.float32)
+    keep = (np.minimum(wide[:, 0], w - wide[:, 0]) < 110) | (np.minimum(wide[:, 1], h - wide[:, 1]) < 110)
+    pts = np.concatenate([ring, wide[keep]])
+    with Context(max_width=w, max_height=h, nfeatures=500, max_points=2048) as ctx:
+        gp, gs, ge = _check_lk(ctx, a, b, pts)
+        assert 0.2 < gs.mean() < 1.0
+        w2, h2 = w - 37, h - 22
+        _check_lk(ctx, np.ascontiguousarray(a[:h2, :w2]), np.ascontiguousarray(b[:h2, :w2]), pts[(pts[:, 0] < w2 + 3) & (pts[:, 1] < h2 + 3)])
+
+
 def test_lk_four_points_per_wavefront_grouping(ctx720, frames480):
     """The kernel tracks four points per wavefront, one per DPP row: every group size (1 .. 9 points), groups whose rows take
     different branches (a point outside the image next to tracked ones, a point on flat texture, border points whose tiles
