@@ -10,7 +10,8 @@ FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-ma
 pids=()
 for f in $root/ros2_mono_vo_amd/csrc/*.hip; do
   b=$(basename $f .hip)
-  /opt/rocm/bin/hipcc $FLAGS "$@" -c $f -o $out/$b.o 2> $out/$b.log &
+  extra=""; [ $b = match ] && extra="-mllvm -amdgpu-mfma-vgpr-form"   # as csrc/Makefile
+  /opt/rocm/bin/hipcc $FLAGS $extra "$@" -c $f -o $out/$b.o 2> $out/$b.log &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
