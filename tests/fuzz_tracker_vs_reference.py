@@ -2,12 +2,18 @@
 `python3 tests/fuzz_tracker_vs_reference.py SEED [TRIALS]`.  Each trial renders B = 6 streams of random kind (lateral / pan /
 fast / cut) and scene seed, runs mvo_batch_track over 28 frames and the reference Tracker (tests/track_ref.py over the
 oracle) on each stream, and compares every integer of every frame result and the poses (contract: 1e-4; the largest
-difference is reported).  A stream is no longer compared after its reference pose stops being a pose (|rvec| > pi/2 or
-|tvec| > 100: both sides then follow garbage).  Exit code 1 on any mismatch.
+difference is reported).  A stream is no longer compared after its reference pose stops being a pose: |rvec| > pi/2 or
+|tvec| > 100, or the REFERENCE's own translation jumps by more than 2 units between consecutive frames (the scenes move
+~0.1 per frame): its LM has then left the track for another minimum of an ill-conditioned refit, which amplifies the
+1e-9 of the summation order to 1e-3, and both sides follow garbage from there on (counted as `jumps`).  Exit code 1 on any
+mismatch.
 Round 2: seed 5 x 5 trials: 699 frame results, identical, poses <= 1e-9; seed 9 x 30 trials: 4023 frame results, all integers
 identical, poses <= 4e-8 except on two frames of one stream (fast, scene 334, frames 25 and 27) where the REFERENCE's LM
 itself jumps to another minimum (t = (-1.6, 1.9, -9.3) on a track at (-3.8, -0.4, -0.7)) and the two sides agree to 7e-7 /
-1.7e-5 there - the ill-conditioned refit of DESIGN 5 amplifying the 1e-9 of the summation order."""
+1.7e-5 there - the ill-conditioned refit of DESIGN 5 amplifying the 1e-9 of the summation order.
+Round 3 (final code): seed 13 x 12 trials: 1583 frame results, all integers identical; one frame of one stream (fast, scene
+302, frame 25) is such a jump - reference t (-3.35, -0.16, -0.78) -> (-2.81, -2.93, -9.31), the device 9e-4 beside it -
+and is what the jump rule above now excludes."""
 import os
 import sys
 import time
@@ -28,7 +34,7 @@ def run(seed=1, trials=4, B=6, N=28, verbose=True):
     rng = np.random.default_rng(seed)
     NF = 1000
     K = synth.default_K(TS.W, TS.H)
-    bad = frames_checked = 0
+    bad = frames_checked = jumps = 0
     worst = 0.0
     t0 = time.time()
     for trial in range(trials):
@@ -41,7 +47,7 @@ def run(seed=1, trials=4, B=6, N=28, verbose=True):
                 for f in range(N):
                     ctx.batch_preload_frame(s, f, data[s][0][f])
             nk = ctx.batch_seed(0)
-            refs, live = [], [True] * B
+            refs, live, last_t = [], [True] * B, [None] * B
             for s, (fr, d0) in enumerate(data):
                 r = TrackRef(K, NF)
                 n, xy, lm = r.seed(fr[0], TS.depth_landmarks(K, d0))
@@ -57,6 +63,12 @@ def run(seed=1, trials=4, B=6, N=28, verbose=True):
                     if (e["flags"] & _lib.STEP_POSE) and (np.linalg.norm(e["rvec"]) > np.pi / 2 or np.linalg.norm(e["tvec"]) > 100):
                         live[s] = False
                         continue
+                    if e["flags"] & _lib.STEP_POSE:
+                        if last_t[s] is not None and np.linalg.norm(np.asarray(e["tvec"]) - last_t[s]) > 2.0:
+                            live[s] = False
+                            jumps += 1
+                            continue
+                        last_t[s] = np.asarray(e["tvec"], float).copy()
                     frames_checked += 1
                     keys = [key for key in INT_KEYS if int(getattr(out[s], key)) != int(e[key])]
                     if e["flags"] & _lib.STEP_POSE and not keys:
@@ -71,7 +83,7 @@ def run(seed=1, trials=4, B=6, N=28, verbose=True):
         print(f"trial {trial}: kinds {kinds} scenes {seeds}  {time.time() - t0:.0f} s", flush=True)
     if verbose:
         print(f"tracker fuzz done: {trials} trials x {B} streams x {N - 1} frames, {frames_checked} frame results compared, mismatches {bad}, "
-              f"largest pose difference {worst:.3g}", flush=True)
+              f"largest pose difference {worst:.3g}, reference jumps excluded {jumps}", flush=True)
     return frames_checked, bad, worst
 
 
