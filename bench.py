@@ -309,9 +309,9 @@ def main():
             pmc = run_pmc(args)
         if "valu_instructions_per_point" not in pmc:      # the probe is best effort: fall back to the committed passes, labelled as such
             try:
-                old = json.load(open(os.path.join(ROOT, "profiles", "r03_lk_pmc.json")))
+                old = json.load(open(os.path.join(ROOT, "profiles", "r03_k_lk_pmc.json")))
                 pmc.update({k: old[k] for k in ("valu_instructions_per_point", "hbm_read_bytes_per_point", "hbm_write_bytes_per_point") if k in old})
-                pmc["fallback"] = "counters from the committed profiles/r03_lk_pmc.json (" + old.get("source", "") + "), NOT from this run"
+                pmc["fallback"] = "counters from the committed profiles/r03_k_lk_pmc.json (" + old.get("source", "") + "), NOT from this run"
             except Exception:
                 pass
 

@@ -508,13 +508,6 @@ __device__ __forceinline__ void lk_track_group(const LkArgs& A, LkGroupLds& S, c
   const float FLT_SCALE = 1.f / (1 << 20);
   const float half = (LK_WIN - 1) * 0.5f;
   const double cnd = (double)A.cn;
-  int sr[LK_NS], sc[LK_NS];   // row and first column of the lane's segments
-#pragma unroll
-  for (int k = 0; k < LK_NS; k++) {
-    const int s = l + 16 * k;
-    sr[k] = __umul24(s, 21846) >> 16;   // s / 3 for s < 2^15
-    sc[k] = (s - 3 * sr[k]) * 7;
-  }
   const bool last_active = l < 15;   // segment 63 (k = 3, l = 15) does not exist
 
   int status = 1;
@@ -526,6 +519,18 @@ __device__ __forceinline__ void lk_track_group(const LkArgs& A, LkGroupLds& S, c
 
   for (int level = A.nlevels - 1; level >= 0; level--) {
     const LkLevelDesc lv = A.lv[level];
+    // Row and first column of the lane's segments, from an opaque copy of the lane index: computed here they cost 12
+    // instructions per level; computed once per wavefront the compiler hoists every LDS offset derived from them out of the
+    // level loop as well and spills them (scratch traffic of ~1.5 KB per point, PMC).
+    int lq = l;
+    asm volatile("" : "+v"(lq));
+    int sr[LK_NS], sc[LK_NS];
+#pragma unroll
+    for (int k = 0; k < LK_NS; k++) {
+      const int s = lq + 16 * k;
+      sr[k] = __umul24(s, 21846) >> 16;   // s / 3 for s < 2^15
+      sc[k] = (s - 3 * sr[k]) * 7;
+    }
     const u8* I = lv.I + (size_t)slot * lv.stride;
     const u8* J = lv.J + (size_t)slot * lv.stride;
     bool go = valid;
@@ -782,12 +787,15 @@ __device__ __forceinline__ void lk_track_group(const LkArgs& A, LkGroupLds& S, c
     }
   }
   if (valid && l == 0) {
-    A.next_pts[2 * pidx] = sx;
-    A.next_pts[2 * pidx + 1] = sy;
-    A.status[pidx] = (u8)status;
-    A.err[pidx] = errv;
+    int slot_o = slot;                 // (opaque: the output addresses are formed here, not kept in registers - or scratch - from the top)
+    asm volatile("" : "+v"(slot_o));
+    const size_t po = (size_t)slot_o * A.maxpts + p;
+    A.next_pts[2 * po] = sx;
+    A.next_pts[2 * po + 1] = sy;
+    A.status[po] = (u8)status;
+    A.err[po] = errv;
 #ifdef LK_ITER_STATS
-    A.err[pidx] = (float)(st_own + 100 * st_trips + 10000 * st_jl);
+    A.err[po] = (float)(st_own + 100 * st_trips + 10000 * st_jl);
 #endif
   }
 }
