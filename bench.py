@@ -7,7 +7,7 @@ solvePnPRansac -> should_add_keyframe -> [findHomography + findFundamentalMat ->
 triangulate + landmark hand-over]].  Streams are DISTINCT rendered scenes with true parallax (synth_gpu: own billboard
 layout, trajectory and noise per stream), seeded with landmarks from the renderer's depth.  Default workload = config C3:
 1280x720, 2000 ORB features; `--width/--height/--nfeatures` select C2 (640x480 / 1000) or C4 (1920x1080 / 4000).
-Per GPU: C contexts x B streams (default 4 x 256), stepped asynchronously so that the one-wavefront-per-stream RANSAC
+Per GPU: C contexts x B streams (default 4 x 512 up to 1280x720, 4 x 256 above), stepped asynchronously so that the one-wavefront-per-stream RANSAC
 chains of one context run beside the wide LK / ORB kernels of another; contexts start 0..10 frames apart so that their
 key-frame steps (every 11th frame under the reference's policy) do not coincide.
 
