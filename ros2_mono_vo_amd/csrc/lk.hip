@@ -308,8 +308,11 @@ __global__ __launch_bounds__(256) void lk_border_kernel(LkBorderArgs A) {
   u8* img = A.img[k] + (size_t)blockIdx.y * A.img_stride;
   const u8* rp = img + (ptrdiff_t)d_reflect101(y, h) * pitch;
   unsigned v = 0;
+  if (x0 >= 0 && x0 + 4 <= w) v = *(const unsigned*)(rp + x0);   // three quarters of the threads: a border row above / below the image columns
+  else {
 #pragma unroll
-  for (int b = 0; b < 4; b++) v |= (unsigned)rp[d_reflect101(x0 + b, w)] << (8 * b);
+    for (int b = 0; b < 4; b++) v |= (unsigned)rp[d_reflect101(x0 + b, w)] << (8 * b);
+  }
   *(unsigned*)(img + (ptrdiff_t)y * pitch + x0) = v;
 }
 
@@ -644,7 +647,8 @@ __device__ __forceinline__ void lk_track_group(const LkArgs& A, LkGroupLds& S, c
             }
 #pragma unroll
             for (int i = 0; i < 7; i++)   // kept as the start value of the iteration's accumulator (lk_seg_diff)
-              Iv[k][i] = 256 - (descale(lk_dot2(V[i + 1], Wb, lk_dot2(V[i], Wa, 0)), 14 - 5) << 9);
+              // 256 - (descale(sum, 14 - 5) << 9) with the rounding constant as the accumulator's start value: (x >> 9) << 9 == x & ~511
+              Iv[k][i] = 256 - (lk_dot2(V[i + 1], Wb, lk_dot2(V[i], Wa, 1 << (14 - 5 - 1))) & ~511);
           }
           const unsigned* d0 = (const unsigned*)&S.s.dt[sr[k] * LK_DT + sc[k]];
           const unsigned* d1 = d0 + LK_DT;
@@ -658,8 +662,8 @@ __device__ __forceinline__ void lk_track_group(const LkArgs& A, LkGroupLds& S, c
           int ixv[7], iyv[7];
 #pragma unroll
           for (int i = 0; i < 7; i++) {
-            ixv[i] = descale(lk_dot2(XV[i + 1], Wb, lk_dot2(XV[i], Wa, 0)), 14);
-            iyv[i] = descale(lk_dot2(YV[i + 1], Wb, lk_dot2(YV[i], Wa, 0)), 14);
+            ixv[i] = lk_dot2(XV[i + 1], Wb, lk_dot2(XV[i], Wa, 1 << 13)) >> 14;   // descale(sum, 14), the rounding constant riding in the accumulator
+            iyv[i] = lk_dot2(YV[i + 1], Wb, lk_dot2(YV[i], Wa, 1 << 13)) >> 14;
           }
 #pragma unroll
           for (int j = 0; j < 3; j++) { IxP[k][j] = lk_pack16(ixv[2 * j], ixv[2 * j + 1]); IyP[k][j] = lk_pack16(iyv[2 * j], iyv[2 * j + 1]); }
