@@ -21,7 +21,13 @@
 // comp(a, b) = a.response > b.response throughout (KeypointResponseGreater).
 #include "mvo_internal.h"
 
+// threads per (stream, level) job.  A job is a chain of barrier-separated passes over its candidates, each thread walking a
+// contiguous chunk.  Per key-frame step of 512 streams ALONE (4096 jobs): 128 threads 2.71 ms, 256: 2.50, 512: 2.09, 1024: 2.43 -
+// but beside three other contexts the 512-thread workgroup places worse (stage 1.03 against 0.81 ms, bench 99.1 against 101.7 k
+// frames/s), so 256 it is; an LDS array of 2048 instead of 4096 entries (twice the workgroups per CU): 3.00 ms.
+#ifndef RB_T
 #define RB_T 256
+#endif
 
 struct RbShared {
   int wsumL[RB_T / 64], wsumR[RB_T / 64];
@@ -265,7 +271,9 @@ struct OrbSelArgs {
 // Levels with at most RB_LDS_CAP candidates (at 720p: all of them, level 0 has ~2-3 k) keep the (response, index) array
 // in LDS for both passes: every introselect round is a handful of dependent passes over it, and from LDS a round
 // costs a fraction of the L2 round trips (the rank-swap staging buffers stay in global memory).
+#ifndef RB_LDS_CAP
 #define RB_LDS_CAP 4096
+#endif
 __global__ __launch_bounds__(RB_T) void orb_select_kernel(OrbSelArgs A) {
   __shared__ RbShared S;
   __shared__ uint2 s_a[RB_LDS_CAP];

@@ -13,7 +13,8 @@ itself jumps to another minimum (t = (-1.6, 1.9, -9.3) on a track at (-3.8, -0.4
 1.7e-5 there - the ill-conditioned refit of DESIGN 5 amplifying the 1e-9 of the summation order.
 Round 3 (final code): seed 13 x 12 trials: 1583 frame results, all integers identical; one frame of one stream (fast, scene
 302, frame 25) is such a jump - reference t (-3.35, -0.16, -0.78) -> (-2.81, -2.93, -9.31), the device 9e-4 beside it -
-and is what the jump rule above now excludes."""
+and is what the jump rule above now excludes; seed 17 x 14 trials (final code): 1956 frame results, identical, poses <= 5.2e-9,
+three such jumps excluded."""
 import os
 import sys
 import time
