@@ -122,8 +122,11 @@ int mvo_match_knn2_ratio(mvo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* 
 
 /* ---- a3: Tracker::track_frame_with_optical_flow (src/tracker.cpp:58-90) -------------------------
  * cv::calcOpticalFlowPyrLK(prev, next, prev_pts, next_pts, status, err) with default arguments.
- * Images mono8 or BGR8 with identical channels (the reference's mono8->BGR8 case); cfg.lk_channels
- * carries the channel count semantics. */
+ * `channels`: 1 (mono8), 3 / -3 (BGR8 / RGB8), 4 / -4 (BGRA8 / RGBA8, alpha ignored).  The reference tracks on the BGR8 image
+ * (src/mono_vo.cpp:94): a mono8 plane, or a colour image whose three channels are identical everywhere, is tracked as ONE
+ * plane with every sum scaled by cfg.lk_channels (exactly what three identical channels give); a colour pair whose channels
+ * differ is tracked over its three channel planes (calcOpticalFlowPyrLK on CV_8UC3: window rows of 3 * 21 interleaved elements).
+ * The frame-batch tracker (mvo_batch_*) keeps mono8 rings and still refuses true colour. */
 int mvo_lk_track(mvo_ctx* ctx, const uint8_t* prev, const uint8_t* next, int w, int h, int stride,
                  int channels, const float* prev_pts, int n, float* next_pts, uint8_t* status, float* err);
 /* cv::pyrDown building block (parity tests). dst is ((w+1)/2) x ((h+1)/2). */

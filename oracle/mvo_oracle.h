@@ -12,6 +12,10 @@ int orc_pyrdown(const unsigned char* src, int w, int h, int stride, unsigned cha
 int orc_lk_track(const unsigned char* prev, const unsigned char* next, int w, int h, int stride, int cn,
                  const float* prev_pts, int n, float* next_pts, unsigned char* status, float* err,
                  int win, int max_level, int max_count, double epsilon, double min_eig_thr);
+/* calcOpticalFlowPyrLK on a true-colour pair (CV_8UC3 / 8UC4 rows of `bpp` interleaved bytes per pixel, first three tracked) */
+int orc_lk_track_color(const unsigned char* prev, const unsigned char* next, int w, int h, int stride, int bpp,
+                       const float* prev_pts, int n, float* next_pts, unsigned char* status, float* err, int win, int max_level,
+                       int max_count, double epsilon, double min_eig_thr);
 
 int orc_fast9_nms(const unsigned char* img, int w, int h, int stride, int threshold, int* xys, int cap);
 int orc_retain_best(const float* resp, int n, int n_keep, int depth_limit, int* out_idx);

@@ -14,6 +14,10 @@
 // Channel semantics: the reference converts every image to BGR8 (src/mono_vo.cpp:94) so LK runs on
 // 3 identical channels.  With identical channels every integer sum is exactly cn x the 1-channel sum;
 // `cn` reproduces that (it matters for minEig, whose denominator has no cn — SURVEY A.3.6).
+// True-colour input (orc_lk_track_planes): OpenCV treats a window row of a cn-channel image as cn * winSize.width interleaved
+// elements - pyrDown, the Scharr derivative and the bilinear template are per channel, and the five normal-equation sums and
+// the error sum simply run over all of them (lkpyramid.cpp: `x < winSize.width * cn`); the scale constants keep cn = 3.  So the
+// planes are processed like independent images and their integer sums added before the one conversion to float.
 #include "orc_common.h"
 #include "mvo_oracle.h"
 
@@ -90,27 +94,36 @@ extern "C" int orc_pyrdown(const unsigned char* src, int w, int h, int stride, u
   return 0;
 }
 
-extern "C" int orc_lk_track(const unsigned char* prev, const unsigned char* next, int w, int h,
-                            int stride, int cn, const float* prev_pts, int n, float* next_pts,
-                            unsigned char* status, float* err, int win, int max_level,
-                            int max_count, double epsilon, double min_eig_thr) {
+// `np` planes per image (1: one plane whose sums are scaled by cn, the replicated-mono case; 3: the channels of a true-colour
+// image, cn = 3 in the scale constants only).  plane c of an image: base + c * plane_step, pixels pixel_step bytes apart.
+static int lk_track_core(const unsigned char* prev, const unsigned char* next, int w, int h, int stride, int pixel_step,
+                         int plane_step, int np, int cn, const float* prev_pts, int n, float* next_pts,
+                         unsigned char* status, float* err, int win, int max_level,
+                         int max_count, double epsilon, double min_eig_thr) {
   if (cn < 1) cn = 1;
+  const int mult = np == 1 ? cn : 1;   // the factor that stands in for the channels that are not there
   // buildOpticalFlowPyramid: stop when the next level would be <= winSize in either dimension.
-  std::vector<Img> P(1), N(1);
-  P[0].w = N[0].w = w; P[0].h = N[0].h = h;
-  P[0].d.resize((size_t)w * h); N[0].d.resize((size_t)w * h);
-  for (int y = 0; y < h; y++) {
-    memcpy(&P[0].d[(size_t)y * w], prev + (size_t)y * stride, w);
-    memcpy(&N[0].d[(size_t)y * w], next + (size_t)y * stride, w);
-  }
+  std::vector<std::vector<Img>> PP(np, std::vector<Img>(1)), NN(np, std::vector<Img>(1));
   int levels = 0;
-  for (int l = 1; l <= max_level; l++) {
-    int sw = (P[l - 1].w + 1) / 2, sh = (P[l - 1].h + 1) / 2;
-    if (sw <= win || sh <= win) break;
-    P.emplace_back(); N.emplace_back();
-    pyr_down(P[l - 1], P[l]);
-    pyr_down(N[l - 1], N[l]);
-    levels = l;
+  for (int c = 0; c < np; c++) {
+    std::vector<Img>& P = PP[c];
+    std::vector<Img>& N = NN[c];
+    P[0].w = N[0].w = w; P[0].h = N[0].h = h;
+    P[0].d.resize((size_t)w * h); N[0].d.resize((size_t)w * h);
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < w; x++) {
+        P[0].d[(size_t)y * w + x] = prev[(size_t)y * stride + (size_t)x * pixel_step + (size_t)c * plane_step];
+        N[0].d[(size_t)y * w + x] = next[(size_t)y * stride + (size_t)x * pixel_step + (size_t)c * plane_step];
+      }
+    levels = 0;
+    for (int l = 1; l <= max_level; l++) {
+      int sw = (P[l - 1].w + 1) / 2, sh = (P[l - 1].h + 1) / 2;
+      if (sw <= win || sh <= win) break;
+      P.emplace_back(); N.emplace_back();
+      pyr_down(P[l - 1], P[l]);
+      pyr_down(N[l - 1], N[l]);
+      levels = l;
+    }
   }
   // criteria clamp + square (calcOpticalFlowPyrLK prologue)
   max_count = std::min(std::max(max_count, 0), 100);
@@ -121,16 +134,16 @@ extern "C" int orc_lk_track(const unsigned char* prev, const unsigned char* next
   const int W_BITS = 14;
   const float FLT_SCALE = 1.f / (1 << 20);
   const float half = (win - 1) * 0.5f;
-  std::vector<short> Iw((size_t)win * win), dIw((size_t)win * win * 2);
+  std::vector<short> Iw((size_t)np * win * win), dIw((size_t)np * win * win * 2);
 
   for (int level = levels; level >= 0; level--) {
-    const Img& I = P[level];
-    const Img& J = N[level];
-    std::vector<short> dI;
-    scharr_deriv(I, dI);
-    auto deriv = [&](int x, int y, int c) -> int {  // zero (BORDER_CONSTANT) outside the image
+    const Img& I = PP[0][level];   // geometry (all planes share it)
+    const Img& J = NN[0][level];
+    std::vector<std::vector<short>> dIs(np);
+    for (int c = 0; c < np; c++) scharr_deriv(PP[c][level], dIs[c]);
+    auto deriv = [&](int ch, int x, int y, int c) -> int {  // zero (BORDER_CONSTANT) outside the image
       if ((unsigned)x >= (unsigned)I.w || (unsigned)y >= (unsigned)I.h) return 0;
-      return dI[((size_t)y * I.w + x) * 2 + c];
+      return dIs[ch][((size_t)y * I.w + x) * 2 + c];
     };
     for (int p = 0; p < n; p++) {
       float px = prev_pts[2 * p] * (float)(1. / (1 << level));
@@ -152,25 +165,29 @@ extern "C" int orc_lk_track(const unsigned char* prev, const unsigned char* next
       int iw10 = cv_round((1.f - a) * b * (1 << W_BITS));
       int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
       int64_t sA11 = 0, sA12 = 0, sA22 = 0;
-      for (int y = 0; y < win; y++)
-        for (int x = 0; x < win; x++) {
-          int X = ipx + x, Y = ipy + y;
-          int ival = descale(I.at(X, Y) * iw00 + I.at(X + 1, Y) * iw01 + I.at(X, Y + 1) * iw10 +
-                             I.at(X + 1, Y + 1) * iw11, W_BITS - 5);
-          int ixval = descale(deriv(X, Y, 0) * iw00 + deriv(X + 1, Y, 0) * iw01 +
-                              deriv(X, Y + 1, 0) * iw10 + deriv(X + 1, Y + 1, 0) * iw11, W_BITS);
-          int iyval = descale(deriv(X, Y, 1) * iw00 + deriv(X + 1, Y, 1) * iw01 +
-                              deriv(X, Y + 1, 1) * iw10 + deriv(X + 1, Y + 1, 1) * iw11, W_BITS);
-          Iw[y * win + x] = (short)ival;
-          dIw[(y * win + x) * 2] = (short)ixval;
-          dIw[(y * win + x) * 2 + 1] = (short)iyval;
-          sA11 += (int64_t)ixval * ixval;
-          sA12 += (int64_t)ixval * iyval;
-          sA22 += (int64_t)iyval * iyval;
-        }
-      float A11 = (float)(sA11 * cn) * FLT_SCALE;
-      float A12 = (float)(sA12 * cn) * FLT_SCALE;
-      float A22 = (float)(sA22 * cn) * FLT_SCALE;
+      for (int ch = 0; ch < np; ch++) {
+        const Img& Ic = PP[ch][level];
+        const size_t o = (size_t)ch * win * win;
+        for (int y = 0; y < win; y++)
+          for (int x = 0; x < win; x++) {
+            int X = ipx + x, Y = ipy + y;
+            int ival = descale(Ic.at(X, Y) * iw00 + Ic.at(X + 1, Y) * iw01 + Ic.at(X, Y + 1) * iw10 +
+                               Ic.at(X + 1, Y + 1) * iw11, W_BITS - 5);
+            int ixval = descale(deriv(ch, X, Y, 0) * iw00 + deriv(ch, X + 1, Y, 0) * iw01 +
+                                deriv(ch, X, Y + 1, 0) * iw10 + deriv(ch, X + 1, Y + 1, 0) * iw11, W_BITS);
+            int iyval = descale(deriv(ch, X, Y, 1) * iw00 + deriv(ch, X + 1, Y, 1) * iw01 +
+                                deriv(ch, X, Y + 1, 1) * iw10 + deriv(ch, X + 1, Y + 1, 1) * iw11, W_BITS);
+            Iw[o + y * win + x] = (short)ival;
+            dIw[(o + y * win + x) * 2] = (short)ixval;
+            dIw[(o + y * win + x) * 2 + 1] = (short)iyval;
+            sA11 += (int64_t)ixval * ixval;
+            sA12 += (int64_t)ixval * iyval;
+            sA22 += (int64_t)iyval * iyval;
+          }
+      }
+      float A11 = (float)(sA11 * mult) * FLT_SCALE;
+      float A12 = (float)(sA12 * mult) * FLT_SCALE;
+      float A22 = (float)(sA22 * mult) * FLT_SCALE;
       float D = A11 * A22 - A12 * A12;
       float minEig = (A22 + A11 - std::sqrt((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) /
                      (float)(2 * win * win);
@@ -193,16 +210,20 @@ extern "C" int orc_lk_track(const unsigned char* prev, const unsigned char* next
         iw10 = cv_round((1.f - a) * b * (1 << W_BITS));
         iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
         int64_t sb1 = 0, sb2 = 0;
-        for (int y = 0; y < win; y++)
-          for (int x = 0; x < win; x++) {
-            int X = inx + x, Y = iny + y;
-            int diff = descale(J.at(X, Y) * iw00 + J.at(X + 1, Y) * iw01 + J.at(X, Y + 1) * iw10 +
-                               J.at(X + 1, Y + 1) * iw11, W_BITS - 5) - Iw[y * win + x];
-            sb1 += (int64_t)diff * dIw[(y * win + x) * 2];
-            sb2 += (int64_t)diff * dIw[(y * win + x) * 2 + 1];
-          }
-        float b1 = (float)(sb1 * cn) * FLT_SCALE;
-        float b2 = (float)(sb2 * cn) * FLT_SCALE;
+        for (int ch = 0; ch < np; ch++) {
+          const Img& Jc = NN[ch][level];
+          const size_t o = (size_t)ch * win * win;
+          for (int y = 0; y < win; y++)
+            for (int x = 0; x < win; x++) {
+              int X = inx + x, Y = iny + y;
+              int diff = descale(Jc.at(X, Y) * iw00 + Jc.at(X + 1, Y) * iw01 + Jc.at(X, Y + 1) * iw10 +
+                                 Jc.at(X + 1, Y + 1) * iw11, W_BITS - 5) - Iw[o + y * win + x];
+              sb1 += (int64_t)diff * dIw[(o + y * win + x) * 2];
+              sb2 += (int64_t)diff * dIw[(o + y * win + x) * 2 + 1];
+            }
+        }
+        float b1 = (float)(sb1 * mult) * FLT_SCALE;
+        float b2 = (float)(sb2 * mult) * FLT_SCALE;
         float dx = (float)((A12 * b2 - A22 * b1) * D);
         float dy = (float)((A12 * b1 - A11 * b2) * D);
         nx += dx; ny += dy;
@@ -228,17 +249,38 @@ extern "C" int orc_lk_track(const unsigned char* prev, const unsigned char* next
         iw10 = cv_round((1.f - aa) * bb * (1 << W_BITS));
         iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
         int64_t se = 0;
-        for (int y = 0; y < win; y++)
-          for (int x = 0; x < win; x++) {
-            int X = inx + x, Y = iny + y;
-            int diff = descale(J.at(X, Y) * iw00 + J.at(X + 1, Y) * iw01 + J.at(X, Y + 1) * iw10 +
-                               J.at(X + 1, Y + 1) * iw11, W_BITS - 5) - Iw[y * win + x];
-            se += std::abs(diff);
-          }
-        float errval = (float)(se * cn);
+        for (int ch = 0; ch < np; ch++) {
+          const Img& Jc = NN[ch][level];
+          const size_t o = (size_t)ch * win * win;
+          for (int y = 0; y < win; y++)
+            for (int x = 0; x < win; x++) {
+              int X = inx + x, Y = iny + y;
+              int diff = descale(Jc.at(X, Y) * iw00 + Jc.at(X + 1, Y) * iw01 + Jc.at(X, Y + 1) * iw10 +
+                                 Jc.at(X + 1, Y + 1) * iw11, W_BITS - 5) - Iw[o + y * win + x];
+              se += std::abs(diff);
+            }
+        }
+        float errval = (float)(se * mult);
         err[p] = errval * 1.f / (32 * win * cn * win);
       }
     }
   }
   return levels;
+}
+
+extern "C" int orc_lk_track(const unsigned char* prev, const unsigned char* next, int w, int h,
+                            int stride, int cn, const float* prev_pts, int n, float* next_pts,
+                            unsigned char* status, float* err, int win, int max_level,
+                            int max_count, double epsilon, double min_eig_thr) {
+  return lk_track_core(prev, next, w, h, stride, 1, 0, 1, cn, prev_pts, n, next_pts, status, err, win, max_level, max_count, epsilon,
+                       min_eig_thr);
+}
+
+// True-colour images, `bpp` (3 or 4) interleaved bytes per pixel of which the first three are tracked (the reference's BGR8;
+// the channel order does not matter to the sums): calcOpticalFlowPyrLK on a CV_8UC3 pair.
+extern "C" int orc_lk_track_color(const unsigned char* prev, const unsigned char* next, int w, int h, int stride, int bpp,
+                                  const float* prev_pts, int n, float* next_pts, unsigned char* status, float* err, int win,
+                                  int max_level, int max_count, double epsilon, double min_eig_thr) {
+  return lk_track_core(prev, next, w, h, stride, bpp, 1, 3, 3, prev_pts, n, next_pts, status, err, win, max_level, max_count, epsilon,
+                       min_eig_thr);
 }

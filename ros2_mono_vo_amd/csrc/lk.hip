@@ -505,12 +505,30 @@ __device__ __forceinline__ void lk_seg_diff(const unsigned* jt, int byte_off, un
 }
 
 // `S` is the row's LDS block, `l` the lane within the row, (slot, p) the row's point; a row without a point has valid = false.
-__device__ __forceinline__ void lk_track_group(const LkArgs& A, LkGroupLds& S, const int slot, const int p, const bool valid, const int l) {
+// True-colour tracking (COLOUR): rows 0..2 of the wavefront hold the three channel planes of ONE point (image slot `islot` =
+// channel, the row's geometry, weights and iteration are the same in all three), and every normal-equation sum is the sum
+// over the channels - cv::calcOpticalFlowPyrLK walks a window row as cn * winSize.width interleaved elements.  A row's sum
+// is the same exact integer (as a double) in each of its 16 lanes: the three are added (exact below 2^53) and every lane gets
+// the total; row 3 idles.
+template <bool COLOUR>
+__device__ __forceinline__ double lk_over_channels(double v) {
+  if (!COLOUR) return v;
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const double a = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+  const double b = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+  const double c = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+  return a + b + c;
+}
+
+// `slot` indexes the points, `islot` the images (the same except for true colour, where islot is the channel plane).
+template <bool COLOUR>
+__device__ __forceinline__ void lk_track_group(const LkArgs& A, LkGroupLds& S, const int slot, const int islot, const int p, const bool valid,
+                                               const int l) {
   const size_t pidx = valid ? (size_t)slot * A.maxpts + p : 0;
   const float ptx = A.prev_pts[2 * pidx], pty = A.prev_pts[2 * pidx + 1];
   const float FLT_SCALE = 1.f / (1 << 20);
   const float half = (LK_WIN - 1) * 0.5f;
-  const double cnd = (double)A.cn;
+  const double cnd = COLOUR ? 1.0 : (double)A.cn;   // one plane stands for cn identical channels; three planes are the channels
   const bool last_active = l < 15;   // segment 63 (k = 3, l = 15) does not exist
 
   int status = 1;
@@ -534,8 +552,8 @@ __device__ __forceinline__ void lk_track_group(const LkArgs& A, LkGroupLds& S, c
       sr[k] = __umul24(s, 21846) >> 16;   // s / 3 for s < 2^15
       sc[k] = (s - 3 * sr[k]) * 7;
     }
-    const u8* I = lv.I + (size_t)slot * lv.stride;
-    const u8* J = lv.J + (size_t)slot * lv.stride;
+    const u8* I = lv.I + (size_t)islot * lv.stride;
+    const u8* J = lv.J + (size_t)islot * lv.stride;
     bool go = valid;
     float px = ptx * (float)(1. / (1 << level));
     float py = pty * (float)(1. / (1 << level));
@@ -675,7 +693,8 @@ __device__ __forceinline__ void lk_track_group(const LkArgs& A, LkGroupLds& S, c
         }
       }
       // per lane: 28 * 4080^2 < 2^29 -> two plain butterfly steps
-      const double sA11 = row_sum_exact_bounded<2>(a11), sA12 = row_sum_exact_bounded<2>(a12), sA22 = row_sum_exact_bounded<2>(a22);
+      const double sA11 = lk_over_channels<COLOUR>(row_sum_exact_bounded<2>(a11)), sA12 = lk_over_channels<COLOUR>(row_sum_exact_bounded<2>(a12)),
+                   sA22 = lk_over_channels<COLOUR>(row_sum_exact_bounded<2>(a22));
       A11 = (float)(sA11 * cnd) * FLT_SCALE;
       A12 = (float)(sA12 * cnd) * FLT_SCALE;
       A22 = (float)(sA22 * cnd) * FLT_SCALE;
@@ -737,7 +756,7 @@ __device__ __forceinline__ void lk_track_group(const LkArgs& A, LkGroupLds& S, c
             }
           }
           // per lane: 28 * 8160 * 4080 < 2^30 -> one plain butterfly step
-          const double sb1 = row_sum_exact_bounded<1>(s1), sb2 = row_sum_exact_bounded<1>(s2);
+          const double sb1 = lk_over_channels<COLOUR>(row_sum_exact_bounded<1>(s1)), sb2 = lk_over_channels<COLOUR>(row_sum_exact_bounded<1>(s2));
           const float b1 = (float)(sb1 * cnd) * FLT_SCALE;
           const float b2 = (float)(sb2 * cnd) * FLT_SCALE;
           const float dx = (A12 * b2 - A22 * b1) * D;
@@ -784,13 +803,13 @@ __device__ __forceinline__ void lk_track_group(const LkArgs& A, LkGroupLds& S, c
             for (int i = 0; i < 7; i++) s1 += abs(diff[i]);
           }
         }
-        const double se = (double)row_sum_i32(s1);  // 16 * 28 * 8160 fits 32 bits
+        const double se = lk_over_channels<COLOUR>((double)row_sum_i32(s1));  // 16 * 28 * 8160 fits 32 bits
         const float errval = (float)(se * cnd);
         errv = errval * 1.f / (float)(32 * LK_WIN * A.cn * LK_WIN);
       }
     }
   }
-  if (valid && l == 0) {
+  if (valid && l == 0 && (!COLOUR || islot == 0)) {
     int slot_o = slot;                 // (opaque: the output addresses are formed here, not kept in registers - or scratch - from the top)
     asm volatile("" : "+v"(slot_o));
     const size_t po = (size_t)slot_o * A.maxpts + p;
@@ -852,12 +871,21 @@ __global__ __launch_bounds__(64, LK_WAVES_PER_EU) void lk_track_kernel(LkArgs A)
       valid = p < min(A.npts[slot], A.maxpts);
       if (!__any(valid)) return;
     }
-    lk_track_group(A, S, slot, p, valid, l);
+    lk_track_group<false>(A, S, slot, slot, p, valid, l);
     if (!persistent) {
       if (!list || blockIdx.x != gridDim.x - 1) return;
       next += LK_G;
     }
   }
+}
+
+// True-colour pair (per-call API): one point per wavefront, its three channel planes on DPP rows 0..2 (image slot = channel).
+__global__ __launch_bounds__(64, LK_WAVES_PER_EU) void lk_track_colour_kernel(LkArgs A) {
+  __shared__ __attribute__((aligned(16))) LkGroupLds lds[LK_G];
+  const int lane = threadIdx.x, g = lane >> 4, l = lane & 15;
+  const int p = blockIdx.x;
+  if (p >= min(A.npts[0], A.maxpts)) return;
+  lk_track_group<true>(A, lds[g], 0, g < 3 ? g : 0, p, g < 3, l);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -970,6 +998,33 @@ int lk_track_device(mvo_ctx* ctx, int prev_set, int cur_set, const LkLevels& L, 
   return MVO_OK;
 }
 
+// True-colour pair of the per-call API: level 0 = the channel planes in lk_c0, levels 1.. = slots 0..2 of the pyramid sets;
+// one single-wavefront workgroup per point (lk_track_colour_kernel).
+int lk_track_colour_device(mvo_ctx* ctx, int prev_set, int cur_set, const LkLevels& L, int n) {
+  LkArgs A;
+  memset(&A, 0, sizeof(A));
+  A.nslots = 1;
+  for (int l = 0; l < L.n; l++) {
+    ImgSet p = lk_imgset(ctx, prev_set, L, l), c = lk_imgset(ctx, cur_set, L, l);
+    A.lv[l].I = p.base; A.lv[l].J = c.base; A.lv[l].stride = p.slot_stride;
+    A.lv[l].w = L.w[l]; A.lv[l].h = L.h[l]; A.lv[l].pitch = L.pitch[l];
+    A.lv[l].pad = l ? MVO_LK_PAD : 0;
+  }
+  A.lv[0].I = ctx->lk_c0[prev_set]; A.lv[0].J = ctx->lk_c0[cur_set]; A.lv[0].stride = ctx->lk_c0_plane;
+  A.nlevels = L.n;
+  A.prev_pts = ctx->d_prev_pts; A.next_pts = ctx->d_next_pts;
+  A.status = ctx->d_status; A.err = ctx->d_err; A.npts = ctx->d_npts;
+  A.maxpts = ctx->maxpts;
+  A.cn = 3;
+  int mc = ctx->cfg.lk_max_count; mc = mc < 0 ? 0 : (mc > 100 ? 100 : mc);
+  double eps = ctx->cfg.lk_epsilon; eps = eps < 0 ? 0 : (eps > 10 ? 10 : eps);
+  A.max_count = mc;
+  A.eps2 = eps * eps;
+  A.min_eig = ctx->cfg.lk_min_eig;
+  if (n > 0) hipLaunchKernelGGL(lk_track_colour_kernel, dim3(n), dim3(64), 0, ctx->stream, A);
+  return MVO_OK;
+}
+
 extern "C" int mvo_pyrdown(mvo_ctx* ctx, const uint8_t* src, int w, int h, int stride, uint8_t* dst,
                            int dstride) {
   if (!ctx || !src || !dst || w < 1 || h < 1 || w > ctx->maxw || h > ctx->maxh) return MVO_E_ARG;
@@ -1012,24 +1067,28 @@ extern "C" int mvo_lk_track(mvo_ctx* ctx, const uint8_t* prev, const uint8_t* ne
   LkLevels L = lk_levels(w, h, ctx->cfg.lk_win, ctx->cfg.lk_max_level);
   int rc;
   ImgSet p0 = lk_imgset(ctx, 0, L, 0), c0 = lk_imgset(ctx, 1, L, 0);
+  // A colour image is reduced to gray (what a replicated mono8 source needs: one plane, sums scaled by lk_channels) AND kept as
+  // its three channel planes: the reference tracks on the BGR8 image (src/mono_vo.cpp:94 -> src/tracker.cpp:68), so when the
+  // channels of either image differ the sums must run over all three.
   if ((rc = upload_gray(ctx, prev, w, h, stride, channels, p0.base, p0.pitch, 0, true))) return rc;
+  if (channels != 1) planes_from_stage(ctx, w, h, channels, ctx->lk_c0[0], p0.pitch, ctx->lk_c0_plane);
   if ((rc = upload_gray(ctx, next, w, h, stride, channels, c0.base, c0.pitch, 0, true))) return rc;
-  if (channels != 1) {
-    int differ = 0;
-    if ((rc = color_channels_differ(ctx, &differ))) return rc;
-    if (differ) {
-      ctx->set_error("mvo_lk_track: true-colour input (channels differ) is not built: LK tracks one plane, which equals the "
-                     "reference's 3-channel LK only for mono8 replicated to BGR8; convert to mono8 or pass a replicated image");
-      return MVO_E_ARG;
-    }
-  }
-  lk_build_pyramid(ctx, 0, L, 1);
-  lk_build_pyramid(ctx, 1, L, 1);
+  if (channels != 1) planes_from_stage(ctx, w, h, channels, ctx->lk_c0[1], c0.pitch, ctx->lk_c0_plane);
+  int differ = 0;
+  if (channels != 1 && (rc = color_channels_differ(ctx, &differ))) return rc;
   MVO_HIP(hipMemcpyAsync(ctx->d_prev_pts, prev_pts, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   int* hn = (int*)ctx->h_pin;
   hn[0] = n;
   MVO_HIP(hipMemcpyAsync(ctx->d_npts, hn, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-  lk_track_device(ctx, 0, 1, L, 1, n);
+  if (differ) {   // true colour: the channel planes are slots 0..2 of the pyramid sets
+    lk_build_pyramid(ctx, 0, L, 3, nullptr, ctx->lk_c0[0], ctx->lk_c0_plane);
+    lk_build_pyramid(ctx, 1, L, 3, nullptr, ctx->lk_c0[1], ctx->lk_c0_plane);
+    lk_track_colour_device(ctx, 0, 1, L, n);
+  } else {
+    lk_build_pyramid(ctx, 0, L, 1);
+    lk_build_pyramid(ctx, 1, L, 1);
+    lk_track_device(ctx, 0, 1, L, 1, n);
+  }
   MVO_HIP(hipMemcpyAsync(next_pts, ctx->d_next_pts, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   MVO_HIP(hipMemcpyAsync(status, ctx->d_status, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   MVO_HIP(hipMemcpyAsync(err, ctx->d_err, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));

@@ -74,6 +74,25 @@ __global__ void color2gray_kernel(const u8* __restrict__ src, int spitch, u8* __
   if (differ && (b != g || g != r)) *differ = 1;   // benign race: every writer stores the same value
 }
 
+// the first three channels of the staged interleaved image as three planes (true-colour LK: the channel order does not matter
+// to the sums, alpha is dropped)
+__global__ void color2planes_kernel(const u8* __restrict__ src, int spitch, u8* __restrict__ dst, int dpitch, size_t plane, int w, int h,
+                                    int bpp) {
+  int x = blockIdx.x * blockDim.x + threadIdx.x;
+  int y = blockIdx.y;
+  if (x >= w) return;
+  const u8* p = src + (size_t)y * spitch + bpp * x;
+  u8* d = dst + (size_t)y * dpitch + x;
+  d[0] = p[0]; d[plane] = p[1]; d[2 * plane] = p[2];
+}
+
+// after upload_gray(.., slot 0) of a colour image: its channel planes from the staging buffer
+void planes_from_stage(mvo_ctx* ctx, int w, int h, int channels, u8* d_dst, int dpitch, size_t plane) {
+  const int bpp = channels < 0 ? -channels : channels;
+  dim3 grid((w + 255) / 256, h);
+  hipLaunchKernelGGL(color2planes_kernel, grid, dim3(256), 0, ctx->stream, ctx->d_stage, align_up(w * bpp, 64), d_dst, dpitch, plane, w, h, bpp);
+}
+
 int upload_gray(mvo_ctx* ctx, const uint8_t* img, int w, int h, int stride, int channels, u8* d_dst,
                 int dpitch, int slot, bool check_identical) {
   if (channels == 1) {
@@ -125,8 +144,10 @@ static int mvo_create_impl(const mvo_config* cfg, mvo_ctx** out) {
   }
   ctx->lk_slot_bytes = off + 256;
   for (int i = 0; i < 2; i++) {
-    MVO_HIP(hipMalloc(&ctx->lk_mem[i], ctx->lk_slot_bytes * ctx->B));
+    MVO_HIP(hipMalloc(&ctx->lk_mem[i], ctx->lk_slot_bytes * (ctx->B > 3 ? ctx->B : 3)));
     MVO_HIP(hipMalloc(&ctx->lk_l0[i], (size_t)L.pitch[0] * L.h[0] + 256));
+    ctx->lk_c0_plane = ((size_t)L.pitch[0] * L.h[0] + 255) & ~(size_t)255;
+    MVO_HIP(hipMalloc(&ctx->lk_c0[i], 3 * ctx->lk_c0_plane + 256));
   }
   size_t np = (size_t)ctx->B * ctx->maxpts;
   MVO_HIP(hipMalloc(&ctx->d_prev_pts, np * 2 * sizeof(float)));
@@ -170,7 +191,7 @@ extern "C" void mvo_destroy(mvo_ctx* ctx) {
   geom_state_destroy(ctx);
   match_state_destroy(ctx);
   orb_state_destroy(ctx);
-  for (int i = 0; i < 2; i++) { (void)hipFree(ctx->lk_mem[i]); (void)hipFree(ctx->lk_l0[i]); }
+  for (int i = 0; i < 2; i++) { (void)hipFree(ctx->lk_mem[i]); (void)hipFree(ctx->lk_l0[i]); (void)hipFree(ctx->lk_c0[i]); }
   (void)hipFree(ctx->d_prev_pts);
   (void)hipFree(ctx->d_next_pts);
   (void)hipFree(ctx->d_status);

@@ -52,6 +52,9 @@ struct mvo_ctx {
                                         // (MVO_LK_PAD rows / columns, MVO_LK_PADR columns on the right), see lk_levels()
   u8* lk_l0[2] = {nullptr, nullptr};    // level 0 of slot 0 only: the per-call API (mvo_lk_track, mvo_pyrdown).  The frame-batch
                                         // tracker reads level 0 in place from the frame ring and keeps no copy of it.
+  u8* lk_c0[2] = {nullptr, nullptr};    // level 0 of a TRUE-COLOUR pair of the per-call API: three channel planes lk_c0_plane bytes apart
+                                        // (the channels are "slots" 0..2 of the pyramid set: lk_mem holds max(B, 3) slots)
+  size_t lk_c0_plane = 0;
   size_t lk_slot_bytes = 0;
   size_t lk_level_off[MVO_LK_MAX_LEVELS] = {0, 0, 0, 0};   // [0] unused
   int lk_cur = 0;  // index of the "cur" set
@@ -251,6 +254,7 @@ void lk_filter_compact_launch(mvo_ctx* ctx, hipStream_t st, const TrkLostPolicy*
 // device-level stage drivers (all slots per launch)
 int lk_build_pyramid(mvo_ctx* ctx, int set, const LkLevels& L, int nslots, hipStream_t st = nullptr, const u8* l0 = nullptr,
                      size_t l0_stride = 0);
+int lk_track_colour_device(mvo_ctx* ctx, int prev_set, int cur_set, const LkLevels& L, int n);   // true-colour pair in lk_c0 / slots 0..2
 int lk_track_device(mvo_ctx* ctx, int prev_set, int cur_set, const LkLevels& L, int nslots, int max_n, hipStream_t st = nullptr,
                     const int* d_work_slot = nullptr, const int* d_pt_base = nullptr, int* d_work_ctr = nullptr,
                     const u8* prev_l0 = nullptr, const u8* cur_l0 = nullptr, size_t l0_stride = 0, int items_bound = -1);
@@ -285,6 +289,7 @@ int geom_triangulate_matches(mvo_ctx* ctx, int nslots, int max_matches, const mv
 // Upload a host image (mono8 or BGR8, arbitrary stride) into a device mono8 ImgSet slot (async on ctx->stream).
 int upload_gray(mvo_ctx* ctx, const uint8_t* img, int w, int h, int stride, int channels, u8* d_dst,
                 int dpitch, int slot, bool check_identical = false);
+void planes_from_stage(mvo_ctx* ctx, int w, int h, int channels, u8* d_dst, int dpitch, size_t plane);   // channel planes of the image upload_gray staged last (slot 0)
 int color_channels_differ(mvo_ctx* ctx, int* differ);   // see color2gray_kernel
 
 // ---- device helpers -------------------------------------------------------------------------------

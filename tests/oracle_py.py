@@ -60,10 +60,15 @@ def lk_track(prev, nxt, pts, cn=3, win=21, max_level=3, max_count=30, eps=0.01, 
     nxt = np.ascontiguousarray(nxt, np.uint8)
     pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
     n = len(pts)
-    h, w = prev.shape
     out = np.zeros((n, 2), np.float32)
     st = np.zeros(n, np.uint8)
     err = np.zeros(n, np.float32)
+    if prev.ndim == 3:      # true colour (H, W, 3 or 4): the sums run over the three channels
+        h, w, bpp = prev.shape
+        lib().orc_lk_track_color(_p(prev), _p(nxt), w, h, w * bpp, bpp, _p(pts), n, _p(out), _p(st), _p(err), win, max_level,
+                                 max_count, C.c_double(eps), C.c_double(min_eig))
+        return out, st, err
+    h, w = prev.shape
     lib().orc_lk_track(_p(prev), _p(nxt), w, h, w, cn, _p(pts), n, _p(out), _p(st), _p(err), win, max_level,
                        max_count, C.c_double(eps), C.c_double(min_eig))
     return out, st, err

@@ -314,11 +314,12 @@ def test_lk_four_points_per_wavefront_grouping(ctx720, frames480):
     _check_lk(ctx720, flat, a, good[:37])
 
 
-def test_lk_colour_input_must_be_replicated_mono(ctx480, frames480):
-    """The reference tracks on the BGR8 image (src/mono_vo.cpp:94 -> src/tracker.cpp:68): three channels in every LK sum.  The
-    device tracks one plane with the sums scaled by lk_channels, which is the same thing only for mono8 replicated to BGR8
-    (then bit-exact vs the 3-channel oracle); true colour is refused instead of silently diverging."""
-    from ros2_mono_vo_amd import MvoError
+def test_lk_colour_input(ctx480, frames480):
+    """The reference tracks on the BGR8 image (src/mono_vo.cpp:94 -> src/tracker.cpp:68): three channels in every LK sum.  For
+    mono8 replicated to BGR8 the device tracks one plane with the sums scaled by lk_channels (bit-exact vs the oracle either
+    way); when the channels differ, the per-call API tracks the three channel planes of each point on three DPP rows of a
+    wavefront and adds their exact sums (csrc/lk.hip, lk_track_colour_kernel) - bit-exact against the oracle's
+    calcOpticalFlowPyrLK on the CV_8UC3 pair, for BGR8 and BGRA8 layouts, incl. points at the image border."""
     a, b = frames480[0], frames480[1]
     pts = np.stack([np.linspace(60, 580, 64), np.linspace(50, 430, 64)], 1).astype(np.float32)
     rep = lambda g: np.stack([g, g, g], -1)
@@ -327,9 +328,33 @@ def test_lk_colour_input_must_be_replicated_mono(ctx480, frames480):
     op, os_, oe = O.lk_track(a, b, pts, cn=3)
     assert np.array_equal(p3, op) and np.array_equal(s3, os_) and np.array_equal(e3, oe)
     assert np.array_equal(p1, p3) and np.array_equal(s1, s3) and np.array_equal(e1, e3)
+    # one pixel with differing channels is enough to take the three-plane path; it must agree with the oracle's colour LK
     col = rep(a).copy()
-    col[100, 100, 2] ^= 0x10                       # one pixel with differing channels
-    with pytest.raises(MvoError) as ei:
-        ctx480.lk_track(col, rep(b), pts)
-    assert ei.value.code == 1 and "true-colour" in str(ei.value)
-    ctx480.lk_track(rep(a), rep(b), pts)            # the flag does not stick
+    col[100, 100, 2] ^= 0x10
+    gp, gs, ge = ctx480.lk_track(col, rep(b), pts)
+    op, os_, oe = O.lk_track(col, rep(b), pts)
+    assert np.array_equal(gp, op) and np.array_equal(gs, os_) and np.array_equal(ge, oe)
+    # a colour pair whose channels differ everywhere; key-points + border / outside / sub-pixel points
+    rng = np.random.default_rng(7)
+    def colour(g):     # scene-locked channels: a gain, the identity and a tone curve of the gray value
+        f = g.astype(np.float64)
+        return np.stack([f * 0.85, f, 255.0 * (f / 255.0) ** 0.7], -1).round().clip(0, 255).astype(np.uint8)
+    ca, cb = colour(a), colour(b)
+    k, _ = O.orb_detect_and_compute(a, 1000)
+    kp = np.stack([k["x"], k["y"]], 1).astype(np.float32)[:300]
+    extra = np.array([[0, 0], [639, 479], [-5, 10], [700, 100], [3.25, 470.75], [320.5, 240.5], [12, 12], [630, 5]], np.float32)
+    allp = np.concatenate([kp, extra])
+    gp, gs, ge = ctx480.lk_track(ca, cb, allp)
+    op, os_, oe = O.lk_track(ca, cb, allp)
+    assert np.array_equal(gs, os_) and np.array_equal(gp, op) and np.array_equal(ge, oe)
+    assert gs[:300].mean() > 0.5
+    m1 = O.lk_track(a, b, allp, cn=3)
+    assert not np.array_equal(op, m1[0])                       # ... and it is not the gray result
+    # BGRA8: alpha is dropped
+    ca4 = np.concatenate([ca, rng.integers(0, 256, ca.shape[:2] + (1,), dtype=np.uint8)], -1)
+    cb4 = np.concatenate([cb, rng.integers(0, 256, cb.shape[:2] + (1,), dtype=np.uint8)], -1)
+    g4 = ctx480.lk_track(ca4, cb4, allp)
+    assert all(np.array_equal(x, y) for x, y in zip(g4, (gp, gs, ge)))
+    ctx480.lk_track(rep(a), rep(b), pts)            # the colour flag does not stick: replicated input is one plane again
+    p3b, s3b, e3b = ctx480.lk_track(rep(a), rep(b), pts)
+    assert np.array_equal(p3b, p3) and np.array_equal(s3b, s3) and np.array_equal(e3b, e3)

@@ -181,6 +181,40 @@ def test_lk_zero_motion_and_translation():
     assert np.all(s1 <= s) and np.abs(p1[s1 > 0] - p[s1 > 0]).max() < 1e-3
 
 
+
+def test_lk_true_colour_known_answers():
+    """calcOpticalFlowPyrLK on a CV_8UC3 pair (orc_lk_track_color): the sums run over the three channels.  Pinned by what must
+    follow from that: (1) three identical channels = the one-plane path with cn = 3, bit for bit; (2) the channel order does not
+    matter; (3) an alpha byte is ignored; (4) a pair whose channels are shifted copies of one texture is tracked to the shift;
+    (5) a third channel that carries nothing (constant) leaves the positions where two copies of the texture put them (up to the
+    minEig gate and float rounding), while the error - the sum of |differences| over 3 x 21 x 21 elements divided by that count -
+    falls to two thirds of the three-identical-channels value."""
+    fr = synth.gen_stream(320, 240, 7, 1)[0]
+    k, _ = O.orb_detect_and_compute(fr, 300)
+    pts = np.stack([k["x"], k["y"]], 1)[:150].astype(np.float32)
+    shifted = np.roll(fr, (2, 3), (0, 1))
+    rep = lambda g: np.stack([g, g, g], -1)
+    mono = O.lk_track(fr, shifted, pts, cn=3)
+    col = O.lk_track(rep(fr), rep(shifted), pts)
+    assert all(np.array_equal(a, b) for a, b in zip(mono, col))                                   # (1)
+    tone = lambda g: np.stack([(g * 0.85).round(), g, 255.0 * (g / 255.0) ** 0.7], -1).round().clip(0, 255).astype(np.uint8)
+    a3, b3 = tone(fr.astype(np.float64)), tone(shifted.astype(np.float64))
+    bgr = O.lk_track(a3, b3, pts)
+    rgb = O.lk_track(a3[:, :, ::-1], b3[:, :, ::-1], pts)
+    assert all(np.array_equal(a, b) for a, b in zip(bgr, rgb))                                    # (2)
+    alpha = np.full(fr.shape + (1,), 77, np.uint8)
+    bgra = O.lk_track(np.concatenate([a3, alpha], -1), np.concatenate([b3, 255 - alpha], -1), pts)
+    assert all(np.array_equal(a, b) for a, b in zip(bgr, bgra))                                   # (3)
+    p, s, e = bgr
+    inner = (pts[:, 0] > 40) & (pts[:, 0] < 280) & (pts[:, 1] > 40) & (pts[:, 1] < 200) & (s > 0)
+    assert inner.sum() > 50 and np.abs(np.median(p[inner] - pts[inner], 0) - [3, 2]).max() < 0.05  # (4)
+    assert not np.array_equal(p, mono[0])                                                         # ... and it is its own computation
+    two = O.lk_track(np.stack([fr, fr, np.full_like(fr, 9)], -1), np.stack([shifted, shifted, np.full_like(fr, 9)], -1), pts)
+    ok = (two[1] > 0) & (mono[1] > 0)
+    assert ok.sum() > 100 and np.abs(two[0][ok] - mono[0][ok]).max() < 2e-2                       # (5) positions
+    assert np.allclose(two[2][ok], mono[2][ok] * (2.0 / 3.0), rtol=0.05, atol=0.02)               # (5) error = sum / (32 * 21 * 3 * 21)
+
+
 # ---- linear algebra ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(3, 3), (4, 4), (7, 9), (12, 12), (6, 4), (6, 5), (5, 9)])
 def test_jacobi_svd_vs_numpy(shape):
