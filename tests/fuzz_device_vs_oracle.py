@@ -26,7 +26,7 @@ def run(seed=1, seconds_a=180, seconds_b=60, verbose=True):
         fr = synth.gen_stream(640, 480, 0x5EED0042, 4)
         k, _ = O.orb_detect_and_compute(fr[0], 1000)
         good = np.stack([k["x"], k["y"]], 1).astype(np.float32)
-        n_lk = n_h = n_f = n_p = 0
+        n_lk = n_h = n_f = n_p = n_col = 0
         while time.time() - t0 < seconds_a:
             # ---- LK: random group sizes, random mix of good / border / outside / sub-pixel points, random frame pair
             n = int(rng.integers(1, 40))
@@ -35,10 +35,17 @@ def run(seed=1, seconds_a=180, seconds_b=60, verbose=True):
             pos = rng.choice(n, m, replace=False)
             pts[pos] = np.stack([rng.uniform(-40, 680, m), rng.uniform(-40, 520, m)], 1).astype(np.float32)
             a, b = fr[int(rng.integers(0, 2))], fr[int(rng.integers(2, 4))]
-            gp, gs, ge = ctx.lk_track(a, b, pts)
-            op, os_, oe = O.lk_track(a, b, pts, cn=3)
+            if rng.integers(0, 5) == 0:   # one case in five as a true-colour pair (three channel planes per point on the device)
+                tone = lambda g: np.stack([(g * 0.85).round(), g, 255.0 * (g / 255.0) ** 0.7], -1).round().clip(0, 255).astype(np.uint8)
+                a, b = tone(a.astype(np.float64)), tone(b.astype(np.float64))
+                gp, gs, ge = ctx.lk_track(a, b, pts)
+                op, os_, oe = O.lk_track(a, b, pts)
+                n_col += 1
+            else:
+                gp, gs, ge = ctx.lk_track(a, b, pts)
+                op, os_, oe = O.lk_track(a, b, pts, cn=3)
             if not (np.array_equal(gp, op) and np.array_equal(gs, os_) and np.array_equal(ge, oe)):
-                bad += 1; print("LK MISMATCH", n, m, flush=True)
+                bad += 1; print("LK MISMATCH", n, m, a.ndim, flush=True)
             n_lk += 1
             # ---- geometry on random scenes
             P = int(rng.integers(8, 400)); outl = float(rng.choice([0.0, 0.1, 0.3, 0.6])); planar = bool(rng.integers(0, 2))
@@ -108,9 +115,9 @@ def run(seed=1, seconds_a=180, seconds_b=60, verbose=True):
                 if not np.array_equal(X3, oX3):
                     bad += 1; print("TRIANGULATE MISMATCH", P, flush=True)
             n_e += 1
-    counts = dict(LK=n_lk, H=n_h, F=n_f, PnP=n_p, ORB=n_orb, match=n_m, E=n_e)
+    counts = dict(LK=n_lk, LK_colour=n_col, H=n_h, F=n_f, PnP=n_p, ORB=n_orb, match=n_m, E=n_e)
     if verbose:
-        print(f"fuzz done: LK {n_lk} H {n_h} F {n_f} PnP {n_p} ORB {n_orb} match {n_m} E/recoverPose/triangulate {n_e} cases, mismatches {bad}, "
+        print(f"fuzz done: LK {n_lk} (true colour {n_col}) H {n_h} F {n_f} PnP {n_p} ORB {n_orb} match {n_m} E/recoverPose/triangulate {n_e} cases, mismatches {bad}, "
               f"{time.time() - t0:.0f} s", flush=True)
     return counts, bad
 
