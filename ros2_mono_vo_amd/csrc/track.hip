@@ -35,7 +35,7 @@ struct TrackState {
   int* d_nkf = nullptr;        // [1]
   int* d_pt_base = nullptr;    // [B+1] LK work list: first item of each slot
   int* d_work_slot = nullptr;  // [B*maxpts] LK work list: slot << 16 | point of each item (trk_worklist_sort_kernel)
-  int* d_work_ctr = nullptr;   // [8] claim counters of the LK work list, one per XCD part
+  int* d_work_ctr = nullptr;   // [8] claim counter of the LK work list in [0] (the XCD-partitioned list of round 2 used all eight)
   int* d_hf_ctr = nullptr;     // [2] slot-queue counters of the H and the F launch (zeroed by slot 0's refine workgroup, trk_policy_keyframe_slot)
   bool res_valid = false;      // h_res holds the results of the step collected last (host-side forecast of the key-frame tests)
   int* d_err = nullptr;        // [1] capacity flags raised on the device
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(1024) void trk_worklist_scan_kernel(const int* __re
   __shared__ int s_run;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) s_run = 0;
-  if (threadIdx.x < 8) work_ctr[threadIdx.x] = 0;   // one claim counter per XCD part of the list (lk_track_kernel)
+  if (threadIdx.x < 8) work_ctr[threadIdx.x] = 0;   // [0]: the claim counter of lk_track_kernel's persistent wavefronts (the rest is spare)
   __syncthreads();
   for (int s0 = 0; s0 < B; s0 += 1024) {
     const int s = s0 + threadIdx.x;
