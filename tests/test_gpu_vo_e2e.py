@@ -27,9 +27,15 @@ def test_essential_ransac_mask_bitexact():
             assert np.abs(R - sc["R"]).max() < 5e-3           # planted motion, noise-limited
 
 
-def test_state_machines_hip_vs_oracle():
+@pytest.mark.parametrize("colour", [False, True])
+def test_state_machines_hip_vs_oracle(colour):
+    """colour: the same sequence as a BGR8 camera would deliver it (three different channels): ORB reduces it to gray, LK tracks
+    on the three channels - the reference's data flow for a colour source (src/mono_vo.cpp:94 -> src/tracker.cpp:68)."""
     K = synth.default_K(vo_scene.W, vo_scene.H)
     fr = vo_scene.frames(8)
+    if colour:
+        tone = lambda g: np.stack([(g * 0.85).round(), g, 255.0 * (g / 255.0) ** 0.7], -1).round().clip(0, 255).astype(np.uint8)
+        fr = [tone(f.astype(np.float64)) for f in fr]
     with Context(max_width=vo_scene.W, max_height=vo_scene.H, nfeatures=1000, max_points=4096) as ctx:
         a = vo.VisualOdometry(ctx, K, nfeatures=1000)
         b = vo.VisualOdometry(OracleBackend(1000), K, nfeatures=1000)
