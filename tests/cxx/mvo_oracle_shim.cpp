@@ -37,7 +37,13 @@ int mvo_match_knn2_ratio(mvo_ctx*, const uint8_t* q, int nq, const uint8_t* t, i
 }
 int mvo_lk_track(mvo_ctx* ctx, const uint8_t* prev, const uint8_t* next, int w, int h, int stride, int channels, const float* prev_pts, int n,
                  float* next_pts, uint8_t* status, float* err) {
-  if (channels != 1) { ctx->err = "the shim tracks mono8 only"; return MVO_E_ARG; }
+  if (channels != 1) {   // BGR8 / RGB8 / BGRA8 / RGBA8: the sums run over the three channels (identical channels give the one-plane result)
+    const int bpp = channels < 0 ? -channels : channels;
+    if (bpp != 3 && bpp != 4) { ctx->err = "channels must be 1, +-3 or +-4"; return MVO_E_ARG; }
+    orc_lk_track_color(prev, next, w, h, stride, bpp, prev_pts, n, next_pts, status, err, ctx->cfg.lk_win, ctx->cfg.lk_max_level,
+                       ctx->cfg.lk_max_count, ctx->cfg.lk_epsilon, ctx->cfg.lk_min_eig);
+    return MVO_OK;
+  }
   orc_lk_track(prev, next, w, h, stride, ctx->cfg.lk_channels, prev_pts, n, next_pts, status, err, ctx->cfg.lk_win, ctx->cfg.lk_max_level,
                ctx->cfg.lk_max_count, ctx->cfg.lk_epsilon, ctx->cfg.lk_min_eig);
   return MVO_OK;
