@@ -984,8 +984,8 @@ int lk_track_device(mvo_ctx* ctx, int prev_set, int cur_set, const LkLevels& L, 
     const unsigned want = (items + LK_G - 1) / LK_G;
     static const bool persistent = !(getenv("MVO_LK_PERSISTENT") && atoi(getenv("MVO_LK_PERSISTENT")) == 0);
     if (!persistent) {
-      A.work_ctr = nullptr;
-      if (want) hipLaunchKernelGGL(lk_track_kernel, dim3(want), dim3(64), 0, st, A);
+      A.work_ctr = nullptr;   // at least one workgroup: the last one walks on past the grid should the bound have been too small
+      hipLaunchKernelGGL(lk_track_kernel, dim3(want ? want : 1u), dim3(64), 0, st, A);
       return MVO_OK;
     }
     const unsigned full = 256u * LK_RESIDENT_PER_CU;
